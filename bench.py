@@ -1,0 +1,157 @@
+"""Headline benchmark: path-tracing throughput on the 1080p triangle-mesh Cornell box.
+
+A step = one full render of BASELINE.json's config 2 (1920x1080, 1024 spp, 8 bounces) on each GPU: rank r
+renders sample indices [r*1024, (r+1)*1024) of the frame (spp-slice sharding, weak scaling) and the
+accumulation buffers are summed onto rank 0 with one RCCL reduce per step. `value` is the whole-job
+Msamples/s (1 sample = one full path of one pixel) with the scene and film resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--spp S] [--depth D] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line. At N=1 it also times the CPU oracle on a bounded sample of the same workload
+(`cpu_baseline`) and derives the algorithmic flops per sample from the oracle's work counters (`roofline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "path-tracer_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+W, H = 1920, 1080
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak: 256 CU x 128 lanes x 2 flop x 2.4 GHz
+
+
+def algorithmic_flops(cnt):
+    """Flops of the reference algorithm for the counted work: 27 per ray-box slab test, 47 per
+    Moller-Trumbore test, 25 per sphere test, 60 per oriented-box test, 250 per shaded hit."""
+    return (27.0 * cnt["nodes_visited"] + 47.0 * cnt["tris_tested"] + 25.0 * cnt["sphere_tests"]
+            + 60.0 * cnt["box_tests"] + 250.0 * cnt["shades"])
+
+
+def cpu_baseline(scene, depth, budget_s=15.0):
+    """Times the CPU oracle (the validated restatement of the reference) on a bounded sample: the same
+    scene and camera at 1/8 resolution per axis, spp chosen so the run takes about budget_s."""
+    from oracle import pyoracle as po
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    small = dict(scene, film=(W // 8, H // 8))
+    S = po.Scene(small)
+    t0 = time.time()
+    S.render(1, depth, threads=cores)
+    t1 = time.time() - t0
+    spp = int(max(2, min(256, budget_s / max(t1, 1e-3))))
+    t0 = time.time()
+    _, _, cnt = S.render(spp, depth, threads=cores, counters=True)
+    dt = time.time() - t0
+    nsamples = (W // 8) * (H // 8) * spp
+    return {"value": nsamples / dt * 1e-6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d, %d spp, depth %d (same scene and camera, 1/64 of the pixels), %.1f s" % (W // 8, H // 8, spp, depth, dt)}, cnt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    os.chdir(ROOT)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import ptamd
+    from scenes import presets
+    ptamd.init(local_rank)
+    ptamd.set_stream(torch.cuda.current_stream().cuda_stream)  # launches and torch events share one stream
+    scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", W, H)
+    pt, cam = ptamd.build_scene(scene)
+    accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    samples = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    film = ptamd.Film(W, H, external=(accum.data_ptr(), samples.data_ptr()))
+    spp_begin = rank * args.spp
+
+    def step(count=False):
+        accum.zero_(); samples.zero_()
+        ptamd.Render(cam, pt, film, args.spp, args.depth, spp_begin=spp_begin, count=count)
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # one RCCL reduce over xGMI per render
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        accum.zero_(); samples.zero_()
+        ev[i][0].record()
+        ptamd.Render(cam, pt, film, args.spp, args.depth, spp_begin=spp_begin)
+        ev[i][1].record()
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # rays per sample of this workload (one extra counted step, outside the timed region)
+    step(count=True)
+    torch.cuda.synchronize()
+    stats = ptamd.RenderStats()
+    rays_per_sample = stats["rays"] / max(1, stats["samples"])
+
+    if rank == 0:
+        samples_per_step = float(W) * H * args.spp * world
+        value = samples_per_step * args.steps / elapsed * 1e-6
+        out = {"metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "triangle-mesh Cornell box (108 triangles, BVH) %dx%d, %d spp per GPU, %d bounces" % (W, H, args.spp, args.depth),
+                          "sharding": "spp-slice per rank + one RCCL reduce of the %.1f MB accumulation buffer per step" % (W * H * 12 / 1e6),
+                          "seed": "0x5EED"},
+               "mrays_per_s": value * rays_per_sample, "rays_per_sample": rays_per_sample,
+               "time_to_1024spp_s": (elapsed / args.steps) * (1024.0 / args.spp) if world == 1 else None,
+               "kernel_ms_per_launch": kernel_ms}
+        if world == 1 and not args.no_cpu:
+            base, cnt = cpu_baseline(scene, args.depth)
+            flops_per_sample = algorithmic_flops(cnt) / max(1, cnt["samples"])
+            achieved = flops_per_sample * float(W) * H * args.spp / (kernel_ms * 1e-3) * 1e-12
+            out["roofline"] = {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                               "kernel": "render_kernel", "flops_per_sample": flops_per_sample,
+                               "note": "fp32 vector ALU bound (no MFMA: not a dense contraction); scene (14 KB) and film "
+                                       "(16 B/pixel/launch) traffic is negligible; algorithmic flops = the reference "
+                                       "algorithm's counted slab/triangle/box tests and shades on this scene"}
+            out["cpu_baseline"] = base
+            out["speedup_vs_cpu_baseline"] = value / base["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

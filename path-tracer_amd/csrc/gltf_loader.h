@@ -1,0 +1,27 @@
+// Minimal glTF 2.0 / GLB ingest. Replaces ModelLoader::LoadGLTF (ModelLoader.h:171-420), which sits on
+// tinygltf + nlohmann json + stb_image: same accepted inputs for the fields the tracer uses (.glb/.gltf,
+// TRIANGLES, float VEC3 POSITION, indexed; optional float NORMAL / TEXCOORD_0; PBR factors, alpha mode,
+// KHR_materials_transmission / _ior; images as 8-bit RGBA), same face order (file order of meshes and
+// primitives, node transforms ignored), same merging of material groups by material name.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/ptamd.h"
+
+namespace ptamd {
+
+struct Model {
+    std::vector<float> positions, normals, texcoords; // 9 / 9 / 6 floats per face
+    std::vector<int32_t> group;
+    std::vector<ptamd_pbr> groups;
+    std::vector<std::string> group_names;
+    std::vector<std::vector<uint8_t>> image_data;   // RGBA8
+    std::vector<ptamd_image> images;                // data pointers into image_data
+    uint32_t num_faces() const { return (uint32_t)group.size(); }
+};
+
+// Throws std::runtime_error with the reference's messages where it has them.
+void load_gltf(const std::string& path, Model& out);
+
+} // namespace ptamd

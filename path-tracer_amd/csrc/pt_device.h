@@ -1,0 +1,529 @@
+// Device functions of the path tracer: intersection, BVH traversal, hit reconstruction, BSDF sampling.
+// gfx950 only (wave64). Reference citations are to /root/reference/src/PathTracer/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pt_types.h"
+
+namespace ptamd {
+
+#define PT_DEV __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+PT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV f3 cross(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+PT_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+PT_DEV float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+PT_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+PT_DEV f3 normalize(f3 a) { return a * frsq(dot(a, a)); }
+PT_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+PT_DEV float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+
+// ---------------------------------------------------------------- random source
+// Counter-based replacement for the reference's thread_local mt19937 (PathTracer.cpp:8-16): a PCG
+// output hash keyed by (seed, pixel, sample, bounce, draw). Bit-identical to oracle/pt_oracle.c.
+PT_DEV uint32_t pcg_hash(uint32_t v)
+{
+    uint32_t s = v * 747796405u + 2891336453u;
+    uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+PT_DEV uint32_t path_key(uint32_t seed_hash, uint32_t pixel, uint32_t sample)
+{
+    uint32_t k = pcg_hash(seed_hash ^ pixel);
+    return pcg_hash(k + sample * 0x9E3779B9u);
+}
+PT_DEV float rand01(uint32_t key, uint32_t bounce, uint32_t draw)
+{
+    uint32_t r = pcg_hash(key + bounce * 8u + draw);
+    return (float)(r >> 8) * 5.9604644775390625e-8f;
+}
+
+// ---------------------------------------------------------------- closest-hit search state
+struct Ray { f3 o, d; };
+
+// What the search keeps per lane: enough to rebuild the full Hit for the winner only.
+struct Best {
+    float t;       // world-space distance (PathTracer.cpp:43 closestT)
+    int obj;       // object index, -1 = miss
+    int tri;       // mesh: triangle index relative to tri_base
+    float u, v;    // mesh: barycentrics
+};
+
+// Sphere::RayIntersect (Sphere.cpp:32-53): returns t or -1.
+PT_DEV float sphere_t(const DObject& ob, const Ray& r, float tMin, float tMax)
+{
+    f3 oc = r.o - mk3(ob.c[0], ob.c[1], ob.c[2]);
+    float a = dot(r.d, r.d);
+    float h = dot(oc, r.d);
+    float c = dot(oc, oc) - ob.radius * ob.radius;
+    float disc = h * h - a * c;
+    if (disc < 0.0f) return -1.0f;
+    float sq = fsqrt(disc);
+    float ia = frcp(a);
+    float t = (-h - sq) * ia;
+    if (t < tMin || t > tMax) {
+        t = (-h + sq) * ia;
+        if (t < tMin || t > tMax) return -1.0f;
+    }
+    return t;
+}
+
+struct BoxLocal { f3 ro, rd, tMin3; float tEntry, tExit; };
+// Box::RayIntersect steps 1-4 (Box.cpp:16-48).
+PT_DEV BoxLocal box_slabs(const DObject& ob, const Ray& r)
+{
+    BoxLocal b;
+    f3 a0 = mk3(ob.ax0[0], ob.ax0[1], ob.ax0[2]), a1 = mk3(ob.ax1[0], ob.ax1[1], ob.ax1[2]), a2 = mk3(ob.ax2[0], ob.ax2[1], ob.ax2[2]);
+    f3 v = r.o - mk3(ob.c[0], ob.c[1], ob.c[2]);
+    b.ro = mk3(dot(a0, v), dot(a1, v), dot(a2, v));
+    b.rd = mk3(dot(a0, r.d), dot(a1, r.d), dot(a2, r.d));
+    const float BIG = 1e30f;
+    f3 inv = mk3(b.rd.x != 0.0f ? frcp(b.rd.x) : -BIG, b.rd.y != 0.0f ? frcp(b.rd.y) : -BIG, b.rd.z != 0.0f ? frcp(b.rd.z) : -BIG);
+    f3 he = mk3(ob.half[0], ob.half[1], ob.half[2]);
+    f3 t1 = (-he - b.ro) * inv, t2 = (he - b.ro) * inv;
+    b.tMin3 = mk3(fminf(t1.x, t2.x), fminf(t1.y, t2.y), fminf(t1.z, t2.z));
+    f3 tMax3 = mk3(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y), fmaxf(t1.z, t2.z));
+    b.tEntry = fmaxf(fmaxf(b.tMin3.x, b.tMin3.y), b.tMin3.z);
+    b.tExit = fminf(fminf(tMax3.x, tMax3.y), tMax3.z);
+    return b;
+}
+// Box.cpp:50-54: returns tHit or -1.
+PT_DEV float box_t(const DObject& ob, const Ray& r, float tMin, float tMax)
+{
+    BoxLocal b = box_slabs(ob, r);
+    if (b.tExit < b.tEntry) return -1.0f;
+    if (b.tExit < tMin) return -1.0f;
+    float tHit = b.tEntry;
+    if (tHit < tMin) tHit = b.tExit;
+    if (tHit < tMin || tHit > tMax) return -1.0f;
+    return tHit;
+}
+// Box.cpp:56-83: world normal (face-forwarded) for the winning hit.
+PT_DEV f3 box_normal(const DObject& ob, const Ray& r, float tHit)
+{
+    BoxLocal b = box_slabs(ob, r);
+    f3 pL = b.ro + b.rd * tHit;
+    f3 he = mk3(ob.half[0], ob.half[1], ob.half[2]);
+    float eps = ob.eps;
+    int axis; float sgn;
+    if (fabsf(pL.x - he.x) <= eps) { axis = 0; sgn = 1.f; }
+    else if (fabsf(pL.x + he.x) <= eps) { axis = 0; sgn = -1.f; }
+    else if (fabsf(pL.y - he.y) <= eps) { axis = 1; sgn = 1.f; }
+    else if (fabsf(pL.y + he.y) <= eps) { axis = 1; sgn = -1.f; }
+    else if (fabsf(pL.z - he.z) <= eps) { axis = 2; sgn = 1.f; }
+    else if (fabsf(pL.z + he.z) <= eps) { axis = 2; sgn = -1.f; }
+    else {
+        if (b.tEntry == b.tMin3.x) { axis = 0; sgn = (b.ro.x + b.tEntry * b.rd.x) > 0.0f ? 1.f : -1.f; }
+        else if (b.tEntry == b.tMin3.y) { axis = 1; sgn = (b.ro.y + b.tEntry * b.rd.y) > 0.0f ? 1.f : -1.f; }
+        else { axis = 2; sgn = (b.ro.z + b.tEntry * b.rd.z) > 0.0f ? 1.f : -1.f; }
+    }
+    f3 ax = axis == 0 ? mk3(ob.ax0[0], ob.ax0[1], ob.ax0[2]) : (axis == 1 ? mk3(ob.ax1[0], ob.ax1[1], ob.ax1[2]) : mk3(ob.ax2[0], ob.ax2[1], ob.ax2[2]));
+    f3 nW = normalize(ax * sgn);
+    return dot(r.d, nW) < 0.0f ? nW : -nW;
+}
+
+// Affine transform by the 3x4 rows stored in DMesh (glm's (m0*x + m1*y) + (m2*z + m3*w) grouping, Mesh.cpp:59-60,166).
+PT_DEV f3 xform_point(const float* m, f3 p)
+{
+    return mk3((m[0] * p.x + m[1] * p.y) + (m[2] * p.z + m[3]),
+               (m[4] * p.x + m[5] * p.y) + (m[6] * p.z + m[7]),
+               (m[8] * p.x + m[9] * p.y) + (m[10] * p.z + m[11]));
+}
+PT_DEV f3 xform_dir(const float* m, f3 d)
+{
+    return mk3((m[0] * d.x + m[1] * d.y) + m[2] * d.z, (m[4] * d.x + m[5] * d.y) + m[6] * d.z, (m[8] * d.x + m[9] * d.y) + m[10] * d.z);
+}
+// transpose(mat3(Minv)) * n (Mesh.cpp:55,229-230): dot of n with column r of mat3(Minv) = minv[4*c + r] over c.
+PT_DEV f3 xform_normal(const float* minv, f3 n)
+{
+    return mk3(minv[0] * n.x + minv[4] * n.y + minv[8] * n.z, minv[1] * n.x + minv[5] * n.y + minv[9] * n.z, minv[2] * n.x + minv[6] * n.y + minv[10] * n.z);
+}
+
+// Mesh::RayTriMT (Mesh.cpp:418-445) on the precomputed v0,e1,e2.
+PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float& t, float& u, float& v, int& group)
+{
+    float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+    group = __float_as_int(q2.y);
+    f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+    f3 p = cross(d, e2);
+    float det = dot(e1, p);
+    if (fabsf(det) < 1e-8f) return false;
+    float invDet = frcp(det);
+    f3 tv = o - v0;
+    u = dot(tv, p) * invDet;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 q = cross(tv, e1);
+    v = dot(d, q) * invDet;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot(e2, q) * invDet;
+    return t > 1e-8f;
+}
+
+PT_DEV float4 sample_nearest(const DScene& sc, int img, float u, float v);
+// Alpha MASK cutout (Mesh.cpp:106-125): false when the texel is below the cutoff.
+PT_DEV bool alpha_pass(const DScene& sc, const DMesh& me, int tri, int group, float u, float v)
+{
+    const DPbr& g = sc.groups[me.group_base + group];
+    if (g.alpha_mode != 1) return true;
+    float alpha = g.base_color_factor[3];
+    if (g.base_color_tex >= 0) {
+        const float4* s = sc.shade + ((size_t)me.tri_base + (size_t)tri) * 7;
+        float4 s4 = s[4], s5 = s[5];
+        float w = 1.0f - u - v;
+        float tu = w * s4.z + u * s5.x + v * s5.z, tv = w * s4.w + u * s5.y + v * s5.w;
+        alpha *= sample_nearest(sc, g.base_color_tex, tu, tv).w;
+    }
+    return !(alpha < g.alpha_cutoff);
+}
+
+// Iterative BVH traversal (replaces the stack walk of Mesh.cpp:79-149): near child first, far child
+// pushed on a per-lane stack kept in LDS (column `lane_slot` of a [depth][block] array).
+template <int BLOCK>
+PT_DEV void mesh_traverse(const DScene& sc, const DMesh& me, f3 o, f3 d, float tMinObj, float& closestT,
+                          int& bestTri, float& bu, float& bv, uint32_t* __restrict__ stack, int slot)
+{
+    const float4* __restrict__ nodes = sc.nodes + (size_t)me.node_base * 4;
+    const float4* __restrict__ tris = sc.tris + (size_t)me.tri_base * 3;
+    const float BIG = 1e30f;
+    f3 inv = mk3(fabsf(d.x) > 1e-30f ? frcp(d.x) : BIG, fabsf(d.y) > 1e-30f ? frcp(d.y) : BIG, fabsf(d.z) > 1e-30f ? frcp(d.z) : BIG);
+    f3 oi = o * inv;
+    int sp = 0;
+    int cur = me.root;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* n = nodes + (size_t)cur * 4;
+            float4 a = n[0], b = n[1], c = n[2], r = n[3];
+            float lx0 = fmaf(a.x, inv.x, -oi.x), lx1 = fmaf(a.w, inv.x, -oi.x);
+            float ly0 = fmaf(a.y, inv.y, -oi.y), ly1 = fmaf(b.x, inv.y, -oi.y);
+            float lz0 = fmaf(a.z, inv.z, -oi.z), lz1 = fmaf(b.y, inv.z, -oi.z);
+            float rx0 = fmaf(b.z, inv.x, -oi.x), rx1 = fmaf(c.y, inv.x, -oi.x);
+            float ry0 = fmaf(b.w, inv.y, -oi.y), ry1 = fmaf(c.z, inv.y, -oi.y);
+            float rz0 = fmaf(c.x, inv.z, -oi.z), rz1 = fmaf(c.w, inv.z, -oi.z);
+            float lmin = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), 0.0f));
+            float lmax = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), closestT));
+            float rmin = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), 0.0f));
+            float rmax = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), closestT));
+            bool hl = lmax >= lmin, hr = rmax >= rmin;
+            int left = __float_as_int(r.x), right = __float_as_int(r.y);
+            if (hl && hr) {
+                bool leftNear = lmin < rmin; // Mesh.cpp:143
+                stack[sp * BLOCK + slot] = (uint32_t)(leftNear ? right : left);
+                ++sp;
+                cur = leftNear ? left : right;
+                continue;
+            }
+            if (hl) { cur = left; continue; }
+            if (hr) { cur = right; continue; }
+        } else {
+            uint32_t code = ~(uint32_t)cur;
+            uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float t, u, v; int group;
+                if (!tri_test(tris + (size_t)(first + i) * 3, o, d, t, u, v, group)) continue;
+                if (t < tMinObj || t >= closestT) continue; // Mesh.cpp:104
+                if ((me.flags & 1u) && group >= 0 && !alpha_pass(sc, me, (int)(first + i), group, u, v)) continue; // Mesh.cpp:106-125
+                closestT = t; bestTri = (int)(first + i); bu = u; bv = v;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = (int)stack[sp * BLOCK + slot];
+    }
+}
+
+// Closest-hit loop of PathTracer::TraceRay (PathTracer.cpp:38-57) over the flat object list.
+template <int BLOCK>
+PT_DEV Best closest_hit(const DScene& sc, const Ray& ray, uint32_t* __restrict__ stack, int slot)
+{
+    const float kTMin = 1e-4f, kTMax = 1e30f;
+    Best best; best.t = kTMax; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
+    for (int i = 0; i < sc.num_objects; ++i) {
+        const DObject& ob = sc.objects[i];
+        if (ob.kind == KIND_SPHERE) {
+            float t = sphere_t(ob, ray, kTMin, best.t);
+            if (t >= 0.0f && t < best.t) { best.t = t; best.obj = i; }
+        } else if (ob.kind == KIND_BOX) {
+            float t = box_t(ob, ray, kTMin, best.t);
+            if (t >= 0.0f && t < best.t) { best.t = t; best.obj = i; }
+        } else {
+            const DMesh& me = sc.meshes[ob.mesh];
+            f3 oo = xform_point(me.minv, ray.o);
+            f3 dd = xform_dir(me.minv, ray.d);
+            float len2 = dot(dd, dd);
+            if (len2 == 0.0f) continue;           // Mesh.cpp:64
+            float dirLen = fsqrt(len2);
+            float invLen = frcp(dirLen);
+            dd = dd * invLen;
+            float tMinObj = kTMin * dirLen;
+            float closestT = best.t * dirLen;      // Mesh.cpp:72-75
+            int tri = -1; float u = 0.f, v = 0.f;
+            mesh_traverse<BLOCK>(sc, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot);
+            if (tri >= 0) {
+                float tW = closestT * invLen;      // Mesh.cpp:249
+                if (tW < best.t) { best.t = tW; best.obj = i; best.tri = tri; best.u = u; best.v = v; }
+            }
+        }
+    }
+    return best;
+}
+
+// Full hit record for the winner (RayObject.h:22-30 with the material by value).
+struct HitInfo {
+    f3 p, n;
+    bool frontFace;
+    f3 albedo; float roughness, metallic;
+    f3 emission;           // emissionColour * emissionStrength (PathTracer.cpp:76)
+    float ior, transmission;
+};
+
+PT_DEV void load_material(const DScene& sc, int idx, HitInfo& h)
+{
+    const float4* m = reinterpret_cast<const float4*>(sc.materials + idx);
+    float4 a = m[0], b = m[1], c = m[2];
+    h.albedo = mk3(a.x, a.y, a.z); h.roughness = a.w; h.metallic = b.x;
+    h.emission = mk3(b.y, b.z, b.w) * c.x; h.ior = c.y; h.transmission = c.z;
+}
+
+// SampleImageNearest (Mesh.cpp:15-37): RGBA8 arena, repeat wrap, no filtering, no sRGB decode.
+PT_DEV float4 sample_nearest(const DScene& sc, int img, float u, float v)
+{
+    DImage im = sc.images[img];
+    if (im.width <= 0 || im.height <= 0) return make_float4(1.f, 1.f, 1.f, 1.f);
+    u = u - floorf(u); v = v - floorf(v);
+    if (u < 0.f) u += 1.0f;
+    if (v < 0.f) v += 1.0f;
+    int x = (int)(u * (float)im.width), y = (int)(v * (float)im.height);
+    x = min(max(x, 0), im.width - 1); y = min(max(y, 0), im.height - 1);
+    uint32_t px = *reinterpret_cast<const uint32_t*>(sc.texels + im.offset + ((size_t)y * im.width + x) * 4);
+    const float k = 255.0f;
+    return make_float4((float)(px & 255u) / k, (float)((px >> 8) & 255u) / k, (float)((px >> 16) & 255u) / k, (float)(px >> 24) / k);
+}
+
+// Mesh::FillMaterialAt (Mesh.cpp:447-486) for a group that samples textures.
+PT_DEV void fill_material_textured(const DScene& sc, const DPbr& g, float u, float v, HitInfo& h)
+{
+    float4 base = make_float4(g.base_color_factor[0], g.base_color_factor[1], g.base_color_factor[2], g.base_color_factor[3]);
+    if (g.base_color_tex >= 0) { float4 t = sample_nearest(sc, g.base_color_tex, u, v); base.x *= t.x; base.y *= t.y; base.z *= t.z; }
+    h.albedo = mk3(base.x, base.y, base.z);
+    float rough = g.roughness_factor, metal = g.metallic_factor;
+    if (g.metallic_roughness_tex >= 0) {
+        float4 t = sample_nearest(sc, g.metallic_roughness_tex, u, v);
+        rough = clampf(t.y * rough, 0.001f, 1.0f);
+        metal = clampf(t.z * metal, 0.0f, 1.0f);
+    }
+    h.roughness = rough; h.metallic = metal;
+    f3 em = mk3(g.emissive_factor[0], g.emissive_factor[1], g.emissive_factor[2]);
+    if (g.emissive_tex >= 0) { float4 t = sample_nearest(sc, g.emissive_tex, u, v); em = em * mk3(t.x, t.y, t.z); }
+    h.emission = em * fsqrt(dot(em, em)); // emissionColour * length(emissionColour)
+    float tr = g.transmission_factor;
+    if (g.transmission_tex >= 0) tr *= sample_nearest(sc, g.transmission_tex, u, v).x;
+    h.transmission = clampf(tr, 0.0f, 1.0f);
+    h.ior = g.ior;
+}
+
+// Rebuilds the Hit of the winning object: Sphere.cpp:55-68, Box.cpp:56-89, Mesh.cpp:153-254.
+PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo& h)
+{
+    const DObject& ob = sc.objects[best.obj];
+    if (ob.kind == KIND_SPHERE) {
+        h.p = ray.o + ray.d * best.t;
+        f3 outward = (h.p - mk3(ob.c[0], ob.c[1], ob.c[2])) * frcp(ob.radius);
+        h.frontFace = dot(ray.d, outward) < 0.0f;
+        h.n = h.frontFace ? outward : -outward;
+        load_material(sc, ob.material, h);
+    } else if (ob.kind == KIND_BOX) {
+        h.p = ray.o + ray.d * best.t;
+        h.n = box_normal(ob, ray, best.t);
+        h.frontFace = false; // Box never reports a front face (Box.cpp:86-89 with PathTracer.cpp:47)
+        load_material(sc, ob.material, h);
+    } else {
+        const DMesh& me = sc.meshes[ob.mesh];
+        const float4* s = sc.shade + ((size_t)me.tri_base + (size_t)best.tri) * 7;
+        float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
+        f3 pa = mk3(s0.x, s0.y, s0.z), pb = mk3(s0.w, s1.x, s1.y), pc = mk3(s1.z, s1.w, s2.x);
+        f3 na = mk3(s2.y, s2.z, s2.w), nb = mk3(s3.x, s3.y, s3.z), nc = mk3(s3.w, s4.x, s4.y);
+        float u = best.u, v = best.v, w = 1.0f - u - v;
+        f3 pObj = (pa * w + pb * u) + pc * v;
+        f3 nObj = normalize((na * w + nb * u) + nc * v);
+        f3 nObjG = normalize(cross(pb - pa, pc - pa));
+        float tu = w * s4.z + u * s5.x + v * s5.z, tv = w * s4.w + u * s5.y + v * s5.w;
+        int group = __float_as_int(s6.x);
+        h.p = xform_point(me.m, pObj);
+        int matIndex = 0; // slot 0 = Material{} defaults (Mesh.cpp:242-246)
+        if (group >= 0) {
+            const DPbr& g = sc.groups[me.group_base + group];
+            if (g.normal_tex >= 0) { // Mesh.cpp:174-226
+                f3 dp1 = pb - pa, dp2 = pc - pa;
+                float du1 = s5.x - s4.z, dv1 = s5.y - s4.w, du2 = s5.z - s4.z, dv2 = s5.w - s4.w;
+                float det = du1 * dv2 - dv1 * du2;
+                f3 T, B;
+                if (fabsf(det) > 1e-8f) {
+                    f3 t = (dp1 * dv2 - dp2 * dv1) * frcp(det);
+                    T = normalize(t - nObj * dot(nObj, t));
+                    B = normalize(cross(nObj, T));
+                } else {
+                    f3 up = (fabsf(nObj.z) < 0.999f) ? mk3(0, 0, 1) : mk3(1, 0, 0);
+                    T = normalize(cross(up, nObj));
+                    B = cross(nObj, T);
+                }
+                float4 tx = sample_nearest(sc, g.normal_tex, tu - floorf(tu), tv - floorf(tv));
+                f3 nts = mk3((tx.x * 2.0f - 1.0f) * g.normal_scale, (tx.y * 2.0f - 1.0f) * g.normal_scale, tx.z * 2.0f - 1.0f);
+                nts = normalize(nts);
+                nObj = normalize(T * nts.x + B * nts.y + nObj * nts.z);
+            }
+            bool textured = (g.base_color_tex >= 0) | (g.metallic_roughness_tex >= 0) | (g.emissive_tex >= 0) | (g.transmission_tex >= 0);
+            if (textured) fill_material_textured(sc, g, tu, tv, h);
+            matIndex = textured ? -1 : g.material; // untextured groups: constant material slot
+        }
+        if (matIndex >= 0) load_material(sc, matIndex, h);
+        f3 nW = normalize(xform_normal(me.minv, nObj));
+        f3 ngW = normalize(xform_normal(me.minv, nObjG));
+        h.frontFace = dot(ray.d, ngW) < 0.0f;
+        h.n = h.frontFace ? nW : -nW;
+    }
+}
+
+// GGX half-vector sample (PathTracer.cpp:125-137, 218-235); the azimuth 2*pi*u1 is taken in turns.
+PT_DEV f3 sample_half(float roughness, float alpha, uint32_t key, uint32_t bounce, uint32_t& draw)
+{
+    if (roughness <= 1e-4f) return mk3(0, 0, 1);
+    float u1 = rand01(key, bounce, draw), u2 = rand01(key, bounce, draw + 1);
+    draw += 2;
+    float a2 = alpha * alpha;
+    float tan2t = a2 * u2 * frcp(fmaxf(1e-6f, 1.0f - u2));
+    float cosT = frsq(1.0f + tan2t);
+    float sinT = fsqrt(fmaxf(0.0f, 1.0f - cosT * cosT));
+    return normalize(mk3(sinT * __builtin_amdgcn_cosf(u1), sinT * __builtin_amdgcn_sinf(u1), cosT));
+}
+PT_DEV float smith_g1(float c, float alpha) // PathTracer.cpp:157-163
+{
+    c = clampf(c, 0.0f, 1.0f);
+    float s = fsqrt(fmaxf(0.0f, 1.0f - c * c));
+    float t = (c > 0.0f) ? s * frcp(c) : 0.0f;
+    float r = fsqrt(1.0f + (alpha * alpha) * (t * t));
+    return 2.0f * frcp(1.0f + r);
+}
+
+// One BSDF step of PathTracer::TraceRay (PathTracer.cpp:78-300) in throughput form.
+// Returns false when the path ends here (specular sample below the surface, PathTracer.cpp:141,239-240).
+// On true: ray/ior are the next segment and `weight` multiplies the throughput.
+PT_DEV bool sample_bsdf(const HitInfo& h, Ray& ray, float& ior, f3& weight, uint32_t key, uint32_t bounce)
+{
+    const float kTMin = 1e-4f;
+    f3 n = normalize(h.n);
+    f3 t = (fabsf(n.z) < 0.999f) ? normalize(mk3(-n.y, n.x, 0.0f)) : normalize(mk3(0.0f, -n.z, n.y));
+    f3 b = cross(n, t);
+    f3 wo = normalize(-ray.d);
+    f3 woL = mk3(dot(wo, t), dot(wo, b), dot(wo, n));
+    float cosNo = fmaxf(0.0f, woL.z);
+    float om = 1.0f - h.metallic;
+    f3 F0 = mk3(0.04f * om + h.albedo.x * h.metallic, 0.04f * om + h.albedo.y * h.metallic, 0.04f * om + h.albedo.z * h.metallic);
+    float roughness = clampf(h.roughness, 0.0f, 1.0f);
+    float alpha = fmaxf(1e-4f, roughness * roughness);
+    uint32_t draw = 0;
+    const float pT = clampf(h.transmission, 0.0f, 1.0f);
+    bool interfaceReflect = false;
+    float selPdf = 1.0f;
+    if (pT > 0.0f && rand01(key, bounce, draw++) < pT) { // PathTracer.cpp:99-204
+        float eta_i = ior;
+        float eta_t = h.frontFace ? h.ior : 1.0f;
+        float eta = eta_i * frcp(eta_t);
+        float cos_i = clampf(dot(-ray.d, n), 0.0f, 1.0f);
+        float r0 = (eta_i - eta_t) * frcp(eta_i + eta_t);
+        r0 *= r0;
+        float F = r0 + (1.0f - r0) * pow5(1.0f - cos_i);
+        float sin2_t = eta * eta * fmaxf(0.0f, 1.0f - cos_i * cos_i);
+        bool TIR = sin2_t > 1.0f;
+        float pR = TIR ? 1.0f : F;
+        if (rand01(key, bounce, draw++) < pR) {
+            interfaceReflect = true;
+            selPdf = fmaxf(1e-3f, pT * pR);
+        } else if (!TIR) {
+            // glm::refract (contrib/include/glm/detail/func_geometric.inl:129-138)
+            float dn = dot(n, ray.d);
+            float k = 1.0f - eta * eta * (1.0f - dn * dn);
+            f3 tdir = (k >= 0.0f) ? (ray.d * eta - n * (eta * dn + fsqrt(k))) : mk3(0, 0, 0);
+            tdir = normalize(tdir);
+            float w = (1.0f - F) * frcp(fmaxf(1e-3f, pT * (1.0f - pR)));
+            weight = mk3(w, w, w);
+            ray.o = h.p + tdir * kTMin;
+            ray.d = tdir;
+            ior = eta_t;
+            return true;
+        }
+    }
+    bool specular = interfaceReflect;
+    float specProb = 1.0f;
+    if (!interfaceReflect) {
+        float fv = pow5(1.0f - clampf(cosNo, 0.0f, 1.0f));
+        f3 Fv = mk3(F0.x + (1.0f - F0.x) * fv, F0.y + (1.0f - F0.y) * fv, F0.z + (1.0f - F0.z) * fv);
+        specProb = clampf((Fv.x + Fv.y + Fv.z) * (1.0f / 3.0f), 0.05f, 0.95f);
+        specular = rand01(key, bounce, draw++) < specProb;
+    }
+    if (specular) { // PathTracer.cpp:124-179 (interface reflection) and 213-283 (specular lobe): same GGX sample
+        f3 hL = sample_half(roughness, alpha, key, bounce, draw);
+        float dwh = dot(woL, hL);
+        f3 wiL = hL * (2.0f * dwh) - woL; // reflect(-woL, hL)
+        if (wiL.z <= 0.0f) return false;
+        f3 wi = normalize(t * wiL.x + b * wiL.y + n * wiL.z);
+        float cosNi = fmaxf(0.0f, wiL.z), cosNh = fmaxf(0.0f, hL.z), cosVh = fmaxf(0.0f, dwh);
+        float fp = pow5(1.0f - clampf(cosVh, 0.0f, 1.0f));
+        f3 F = mk3(F0.x + (1.0f - F0.x) * fp, F0.y + (1.0f - F0.y) * fp, F0.z + (1.0f - F0.z) * fp);
+        float G = smith_g1(cosNo, alpha) * smith_g1(cosNi, alpha);
+        float k = G * cosVh * frcp(fmaxf(1e-6f, cosNo * cosNh));
+        if (interfaceReflect) {
+            k *= frcp(selPdf);
+            ray.o = h.p + wi * kTMin; // offset along the chosen direction, medium unchanged (PathTracer.cpp:174-176)
+        } else {
+            k *= frcp(fmaxf(1e-3f, specProb)) * frcp(fmaxf(1e-3f, 1.0f - pT));
+            ray.o = h.p + n * kTMin;
+            ior = 1.0f; // default-constructed Ray (PathTracer.cpp:278)
+        }
+        weight = F * k;
+        ray.d = wi;
+        return true;
+    }
+    // Lambert (PathTracer.cpp:284-300) with SampleCosineHemisphereLocal (PathTracer.cpp:19-31)
+    float u1 = rand01(key, bounce, draw), u2 = rand01(key, bounce, draw + 1);
+    float r = fsqrt(u1);
+    f3 dl = mk3(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2), fsqrt(fmaxf(0.0f, 1.0f - u1)));
+    f3 dw = normalize(t * dl.x + b * dl.y + n * dl.z);
+    float k = om * frcp(fmaxf(1e-3f, 1.0f - specProb)) * frcp(fmaxf(1e-3f, 1.0f - pT));
+    weight = h.albedo * k;
+    ray.o = h.p + n * kTMin;
+    ray.d = dw;
+    ior = 1.0f;
+    return true;
+}
+
+// Camera::GetRay (Camera.cpp:46-63) with the matrices of CalculateMatrices.
+PT_DEV Ray camera_ray(const DCamera& cam, int px, int py)
+{
+    const float* P = cam.inv_proj; const float* V = cam.inv_view;
+    float nx = (((float)px + 0.5f) / (float)cam.width) * 2.f - 1.f;
+    float ny = (((float)py + 0.5f) / (float)cam.height) * 2.f - 1.f;
+    // invProj * (nx, ny, -+1, 1): (m0*x + m1*y) + (m2*z + m3*w)
+    float nr[4], fr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float xy = P[r] * nx + P[4 + r] * ny;
+        nr[r] = xy + (P[8 + r] * -1.f + P[12 + r]);
+        fr[r] = xy + (P[8 + r] * 1.f + P[12 + r]);
+    }
+    f3 cn = mk3(nr[0] / nr[3], nr[1] / nr[3], nr[2] / nr[3]);
+    f3 cf = mk3(fr[0] / fr[3], fr[1] / fr[3], fr[2] / fr[3]);
+    f3 dc = normalize(cf - cn);
+    f3 dw = mk3(V[0] * dc.x + V[4] * dc.y + V[8] * dc.z, V[1] * dc.x + V[5] * dc.y + V[9] * dc.z, V[2] * dc.x + V[6] * dc.y + V[10] * dc.z);
+    Ray ray;
+    ray.o = mk3(V[12], V[13], V[14]);
+    ray.d = normalize(normalize(dw));
+    return ray;
+}
+
+} // namespace ptamd

@@ -1,0 +1,705 @@
+// C ABI of the path-tracing core (include/ptamd.h): scene container, flattening + upload, film, launches.
+// There is no CPU rendering path in this library: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ptamd.h"
+#include "bvh_build.h"
+#include "gltf_loader.h"
+#include "hostmath.h"
+#include "pt_types.h"
+
+namespace ptamd {
+hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t stream);
+hipError_t launch_camera_rays(const DCamera& cam, float* d_out, hipStream_t stream);
+hipError_t launch_closest_hits(const DScene& sc, const float* d_rays, uint32_t n, float* d_rec, hipStream_t stream);
+hipError_t launch_average(const float* accum, const uint32_t* samples, int n, float* avg, hipStream_t stream);
+hipError_t launch_resolve(const float* accum, const uint32_t* samples, int n, int tonemap, int colourspace, uint32_t* rgba, hipStream_t stream);
+int max_stack_depth();
+} // namespace ptamd
+
+using namespace ptamd;
+
+namespace {
+
+thread_local std::string g_error;
+hipStream_t g_own_stream = nullptr;
+hipStream_t g_stream = nullptr;
+bool g_initialised = false;
+unsigned long long* g_counters = nullptr; // device, 2 x u64
+
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+#define PT_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(PTAMD_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int need_init()
+{
+    if (!g_initialised) return fail(PTAMD_ERR_DEVICE, "ptamd_init has not succeeded: no HIP device selected (there is no CPU fallback)");
+    return PTAMD_OK;
+}
+
+struct HostMesh {
+    Model model;
+    BvhResult bvh;
+    bool bvh_valid = false;
+};
+
+struct HostObject {
+    int kind = KIND_SPHERE;
+    float pos[3] = { 0, 0, 0 }, rot[3] = { 0, 0, 0 }, size[3] = { 1, 1, 1 }; // size: box extents or mesh scale
+    float radius = 1.0f;
+    ptamd_material mat;
+    std::shared_ptr<HostMesh> mesh;
+};
+
+template <class T> struct DevBuf {
+    T* ptr = nullptr; size_t count = 0;
+    int upload(const std::vector<T>& v)
+    {
+        release();
+        count = v.size();
+        size_t bytes = std::max<size_t>(1, count) * sizeof(T);
+        PT_HIP(hipMalloc(reinterpret_cast<void**>(&ptr), bytes));
+        if (count) PT_HIP(hipMemcpy(ptr, v.data(), count * sizeof(T), hipMemcpyHostToDevice));
+        return PTAMD_OK;
+    }
+    void release() { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } count = 0; }
+};
+
+} // namespace
+
+struct ptamd_scene {
+    std::vector<HostObject> objects;
+    float background[3] = { 0.2f, 0.2f, 0.2f };
+    bool committed = false;
+    DevBuf<DObject> d_objects; DevBuf<DMesh> d_meshes; DevBuf<DMaterial> d_materials;
+    DevBuf<DNode> d_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
+    DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
+    DScene dscene;
+    void release()
+    {
+        d_objects.release(); d_meshes.release(); d_materials.release(); d_nodes.release(); d_tris.release();
+        d_shade.release(); d_groups.release(); d_images.release(); d_texels.release();
+    }
+};
+
+struct ptamd_film {
+    int w = 0, h = 0;
+    float* accum = nullptr; uint32_t* samples = nullptr;
+    bool external = false;
+    float* avg = nullptr; uint32_t* rgba = nullptr; // lazily allocated staging
+    void release_staging() { if (avg) (void)hipFree(avg); if (rgba) (void)hipFree(rgba); avg = nullptr; rgba = nullptr; }
+    void release()
+    {
+        release_staging();
+        if (!external) { if (accum) (void)hipFree(accum); if (samples) (void)hipFree(samples); }
+        accum = nullptr; samples = nullptr;
+    }
+};
+
+struct ptamd_model { Model model; };
+
+namespace {
+
+DMaterial to_dmaterial(const ptamd_material& m)
+{
+    DMaterial d; std::memset(&d, 0, sizeof d);
+    std::memcpy(d.albedo, m.albedo, 12); d.roughness = m.roughness; d.metallic = m.metallic;
+    std::memcpy(d.emission_colour, m.emission_colour, 12); d.emission_strength = m.emission_strength;
+    d.ior = m.ior; d.transmission = m.transmission;
+    return d;
+}
+
+// Mesh::FillMaterialAt (Mesh.cpp:447-486) for a group without textures: constant per group.
+ptamd_material group_material(const ptamd_pbr& g)
+{
+    ptamd_material m;
+    for (int k = 0; k < 3; ++k) m.albedo[k] = g.base_color_factor[k];
+    m.roughness = g.roughness_factor; m.metallic = g.metallic_factor;
+    for (int k = 0; k < 3; ++k) m.emission_colour[k] = g.emissive_factor[k];
+    const float* e = g.emissive_factor;
+    m.emission_strength = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    m.transmission = std::min(std::max(g.transmission_factor, 0.0f), 1.0f);
+    m.ior = g.ior;
+    return m;
+}
+
+void rows3x4(const Mat4& M, float out[12])
+{
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) out[4 * r + c] = M.m[c][r];
+}
+
+int check_scene(const ptamd_scene* s) { return s ? PTAMD_OK : fail(PTAMD_ERR_ARG, "null scene handle"); }
+int check_object(const ptamd_scene* s, int object)
+{
+    if (!s) return fail(PTAMD_ERR_ARG, "null scene handle");
+    if (object < 0 || object >= (int)s->objects.size()) return fail(PTAMD_ERR_ARG, "object index out of range");
+    return PTAMD_OK;
+}
+
+int copy_mesh_desc(const ptamd_mesh_desc* d, Model& m)
+{
+    if (!d || !d->positions) return fail(PTAMD_ERR_ARG, "mesh description without positions");
+    if (d->num_faces == 0) return fail(PTAMD_ERR_ARG, "Mesh: no faces in model"); // Mesh.cpp:293
+    if (d->num_faces >= (1u << 28)) return fail(PTAMD_ERR_LIMIT, "mesh has too many faces (limit 2^28 - 1)");
+    const size_t nf = d->num_faces;
+    m.positions.assign(d->positions, d->positions + nf * 9);
+    if (d->normals) m.normals.assign(d->normals, d->normals + nf * 9); else m.normals.assign(nf * 9, 0.0f);
+    if (d->texcoords) m.texcoords.assign(d->texcoords, d->texcoords + nf * 6); else m.texcoords.assign(nf * 6, 0.0f);
+    if (d->group) m.group.assign(d->group, d->group + nf); else m.group.assign(nf, -1);
+    for (size_t i = 0; i < nf; ++i)
+        if (m.group[i] >= (int32_t)d->num_groups) return fail(PTAMD_ERR_ARG, "face material group index out of range");
+    m.groups.assign(d->groups, d->groups + d->num_groups);
+    m.group_names.assign(d->num_groups, std::string());
+    m.image_data.clear(); m.images.clear();
+    for (uint32_t i = 0; i < d->num_images; ++i) {
+        const ptamd_image& im = d->images[i];
+        std::vector<uint8_t> rgba;
+        if (im.width > 0 && im.height > 0 && im.channels > 0 && im.data) {
+            // SampleImageNearest (Mesh.cpp:33-35) fills missing channels with 0 and alpha with 1: expand to RGBA8 once
+            size_t n = (size_t)im.width * im.height;
+            rgba.resize(n * 4);
+            for (size_t p = 0; p < n; ++p)
+                for (int c = 0; c < 4; ++c)
+                    rgba[4 * p + c] = c < im.channels ? im.data[p * im.channels + c] : (c == 3 ? 255 : 0);
+        }
+        m.image_data.push_back(std::move(rgba));
+        ptamd_image o; o.width = m.image_data.back().empty() ? 0 : im.width; o.height = m.image_data.back().empty() ? 0 : im.height;
+        o.channels = 4; o.data = nullptr;
+        m.images.push_back(o);
+    }
+    for (size_t i = 0; i < m.images.size(); ++i) m.images[i].data = m.image_data[i].empty() ? nullptr : m.image_data[i].data();
+    for (const auto& g : m.groups) {
+        const int32_t tex[5] = { g.base_color_tex, g.normal_tex, g.metallic_roughness_tex, g.emissive_tex, g.transmission_tex };
+        for (int32_t t : tex) if (t >= (int32_t)m.images.size()) return fail(PTAMD_ERR_ARG, "material group references an image that was not supplied");
+    }
+    return PTAMD_OK;
+}
+
+DCamera make_camera(const ptamd_camera& c, int w, int h)
+{
+    // Camera::CalculateMatrices (Camera.cpp:22-35)
+    Mat4 R = rotate_euler_xyz(Mat4::identity(), c.rotation_deg);
+    Mat4 worldFromCam = mul(translate(Mat4::identity(), c.position), R);
+    Mat4 proj = perspective(deg2rad(c.fov_deg), (float)w / (float)h, c.near_plane, c.far_plane);
+    Mat4 invProj = inverse(proj);
+    DCamera d; std::memset(&d, 0, sizeof d);
+    std::memcpy(d.inv_proj, invProj.m, 64);
+    std::memcpy(d.inv_view, worldFromCam.m, 64);
+    d.width = w; d.height = h;
+    return d;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* ptamd_last_error(void) { return g_error.c_str(); }
+
+void ptamd_material_default(ptamd_material* m)
+{
+    if (!m) return;
+    m->albedo[0] = m->albedo[1] = m->albedo[2] = 1.0f; m->roughness = 1.0f; m->metallic = 0.0f;
+    m->emission_colour[0] = m->emission_colour[1] = m->emission_colour[2] = 1.0f; m->emission_strength = 0.0f;
+    m->ior = 1.5f; m->transmission = 0.0f;
+}
+void ptamd_pbr_default(ptamd_pbr* p)
+{
+    if (!p) return;
+    p->base_color_tex = p->normal_tex = p->metallic_roughness_tex = p->emissive_tex = p->transmission_tex = -1;
+    for (int k = 0; k < 4; ++k) p->base_color_factor[k] = 1.0f;
+    p->metallic_factor = 0.0f; p->roughness_factor = 1.0f; p->alpha_mode = 0; p->alpha_cutoff = 0.5f; p->normal_scale = 1.0f;
+    p->emissive_factor[0] = p->emissive_factor[1] = p->emissive_factor[2] = 0.0f;
+    p->transmission_factor = 0.0f; p->ior = 1.5f;
+}
+
+int ptamd_init(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(PTAMD_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(PTAMD_ERR_ARG, "device index out of range");
+    PT_HIP(hipSetDevice(device));
+    if (!g_own_stream) { PT_HIP(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking)); g_stream = g_own_stream; }
+    if (!g_counters) PT_HIP(hipMalloc(reinterpret_cast<void**>(&g_counters), 2 * sizeof(unsigned long long)));
+    g_initialised = true;
+    return PTAMD_OK;
+}
+int ptamd_set_stream(void* s)
+{
+    if (int rc = need_init()) return rc;
+    g_stream = reinterpret_cast<hipStream_t>(s);
+    return PTAMD_OK;
+}
+int ptamd_reset_stream(void)
+{
+    if (int rc = need_init()) return rc;
+    g_stream = g_own_stream;
+    return PTAMD_OK;
+}
+int ptamd_synchronize(void)
+{
+    if (int rc = need_init()) return rc;
+    PT_HIP(hipStreamSynchronize(g_stream));
+    return PTAMD_OK;
+}
+
+// ------------------------------------------------------------------------------- scene
+int ptamd_scene_create(ptamd_scene** out)
+{
+    if (!out) return fail(PTAMD_ERR_ARG, "null output pointer");
+    *out = new ptamd_scene();
+    std::memset(&(*out)->dscene, 0, sizeof(DScene));
+    return PTAMD_OK;
+}
+int ptamd_scene_destroy(ptamd_scene* s)
+{
+    if (!s) return PTAMD_OK;
+    s->release();
+    delete s;
+    return PTAMD_OK;
+}
+int ptamd_scene_clear(ptamd_scene* s)
+{
+    if (int rc = check_scene(s)) return rc;
+    s->objects.clear(); s->committed = false;
+    return PTAMD_OK;
+}
+int ptamd_scene_object_count(const ptamd_scene* s) { return s ? (int)s->objects.size() : fail(PTAMD_ERR_ARG, "null scene handle"); }
+
+int ptamd_scene_add_sphere(ptamd_scene* s, const float pos[3], float radius, const ptamd_material* mat)
+{
+    if (int rc = check_scene(s)) return rc;
+    if (!pos) return fail(PTAMD_ERR_ARG, "null position");
+    HostObject o; o.kind = KIND_SPHERE; std::memcpy(o.pos, pos, 12); o.radius = radius;
+    if (mat) o.mat = *mat; else ptamd_material_default(&o.mat);
+    s->objects.push_back(o); s->committed = false;
+    return (int)s->objects.size() - 1;
+}
+int ptamd_scene_add_box(ptamd_scene* s, const float pos[3], const float rot[3], const float size[3], const ptamd_material* mat)
+{
+    if (int rc = check_scene(s)) return rc;
+    if (!pos || !size) return fail(PTAMD_ERR_ARG, "null position or size");
+    HostObject o; o.kind = KIND_BOX; std::memcpy(o.pos, pos, 12); std::memcpy(o.size, size, 12);
+    if (rot) std::memcpy(o.rot, rot, 12);
+    if (mat) o.mat = *mat; else ptamd_material_default(&o.mat);
+    s->objects.push_back(o); s->committed = false;
+    return (int)s->objects.size() - 1;
+}
+static int add_mesh_object(ptamd_scene* s, std::shared_ptr<HostMesh> hm, const float pos[3], const float rot[3], const float scl[3])
+{
+    HostObject o; o.kind = KIND_MESH; o.mesh = std::move(hm);
+    ptamd_material_default(&o.mat);
+    if (pos) std::memcpy(o.pos, pos, 12);
+    if (rot) std::memcpy(o.rot, rot, 12);
+    if (scl) std::memcpy(o.size, scl, 12);
+    s->objects.push_back(o); s->committed = false;
+    return (int)s->objects.size() - 1;
+}
+int ptamd_scene_add_mesh(ptamd_scene* s, const ptamd_mesh_desc* mesh, const float pos[3], const float rot[3], const float scl[3])
+{
+    if (int rc = check_scene(s)) return rc;
+    auto hm = std::make_shared<HostMesh>();
+    if (int rc = copy_mesh_desc(mesh, hm->model)) return rc;
+    return add_mesh_object(s, hm, pos, rot, scl);
+}
+int ptamd_scene_add_mesh_file(ptamd_scene* s, const char* path, const float pos[3], const float rot[3], const float scl[3])
+{
+    if (int rc = check_scene(s)) return rc;
+    if (!path) return fail(PTAMD_ERR_ARG, "null path");
+    auto hm = std::make_shared<HostMesh>();
+    try {
+        load_gltf(path, hm->model);
+    } catch (const std::exception& e) {
+        return fail(PTAMD_ERR_IO, e.what());
+    }
+    if (hm->model.num_faces() == 0) return fail(PTAMD_ERR_IO, "Mesh: no faces in model");
+    if (hm->model.num_faces() >= (1u << 28)) return fail(PTAMD_ERR_LIMIT, "mesh has too many faces (limit 2^28 - 1)");
+    return add_mesh_object(s, hm, pos, rot, scl);
+}
+int ptamd_scene_set_transform(ptamd_scene* s, int object, const float pos[3], const float rot[3], const float size[3])
+{
+    if (int rc = check_object(s, object)) return rc;
+    HostObject& o = s->objects[(size_t)object];
+    if (pos) std::memcpy(o.pos, pos, 12);
+    if (rot) std::memcpy(o.rot, rot, 12);
+    if (size) std::memcpy(o.size, size, 12);
+    s->committed = false;
+    return PTAMD_OK;
+}
+int ptamd_scene_set_radius(ptamd_scene* s, int object, float radius)
+{
+    if (int rc = check_object(s, object)) return rc;
+    if (s->objects[(size_t)object].kind != KIND_SPHERE) return fail(PTAMD_ERR_ARG, "object is not a sphere");
+    s->objects[(size_t)object].radius = radius; s->committed = false;
+    return PTAMD_OK;
+}
+int ptamd_scene_set_material(ptamd_scene* s, int object, const ptamd_material* mat)
+{
+    if (int rc = check_object(s, object)) return rc;
+    if (!mat) return fail(PTAMD_ERR_ARG, "null material");
+    if (s->objects[(size_t)object].kind == KIND_MESH) return fail(PTAMD_ERR_ARG, "mesh materials are edited per group (ptamd_scene_set_mesh_group)");
+    s->objects[(size_t)object].mat = *mat; s->committed = false;
+    return PTAMD_OK;
+}
+int ptamd_scene_set_mesh_group(ptamd_scene* s, int object, uint32_t group, const ptamd_pbr* pbr)
+{
+    if (int rc = check_object(s, object)) return rc;
+    HostObject& o = s->objects[(size_t)object];
+    if (o.kind != KIND_MESH) return fail(PTAMD_ERR_ARG, "object is not a mesh");
+    if (!pbr || group >= o.mesh->model.groups.size()) return fail(PTAMD_ERR_ARG, "bad material group");
+    const int32_t tex[5] = { pbr->base_color_tex, pbr->normal_tex, pbr->metallic_roughness_tex, pbr->emissive_tex, pbr->transmission_tex };
+    for (int32_t t : tex) if (t >= (int32_t)o.mesh->model.images.size()) return fail(PTAMD_ERR_ARG, "material group references an image that was not supplied");
+    o.mesh->model.groups[group] = *pbr; s->committed = false;
+    return PTAMD_OK;
+}
+int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3])
+{
+    if (int rc = check_scene(s)) return rc;
+    if (!rgb) return fail(PTAMD_ERR_ARG, "null colour");
+    std::memcpy(s->background, rgb, 12);
+    if (s->committed) std::memcpy(s->dscene.background, rgb, 12);
+    return PTAMD_OK;
+}
+
+int ptamd_scene_commit(ptamd_scene* s)
+{
+    if (int rc = check_scene(s)) return rc;
+    if (int rc = need_init()) return rc;
+    const int maxDepth = max_stack_depth();
+    std::vector<DObject> objects; std::vector<DMesh> meshes; std::vector<DMaterial> materials;
+    std::vector<DNode> nodes; std::vector<DTri> tris; std::vector<DShade> shade; std::vector<DPbr> groups;
+    std::vector<DImage> images; std::vector<uint8_t> texels;
+    ptamd_material defMat; ptamd_material_default(&defMat);
+    materials.push_back(to_dmaterial(defMat)); // slot 0: Material{} (faces without a material group, Mesh.cpp:242-246)
+    std::vector<std::pair<const HostMesh*, uint32_t>> uploaded; // geometry shared by several instances is stored once
+    struct MeshSlots { uint32_t node_base, tri_base, group_base, image_base; uint32_t flags; };
+    std::vector<MeshSlots> slots;
+
+    for (const HostObject& ho : s->objects) {
+        DObject d; std::memset(&d, 0, sizeof d);
+        d.kind = ho.kind; d.mesh = -1; d.material = 0;
+        if (ho.kind == KIND_SPHERE) {
+            std::memcpy(d.c, ho.pos, 12); d.radius = ho.radius;
+            d.material = (int32_t)materials.size(); materials.push_back(to_dmaterial(ho.mat));
+        } else if (ho.kind == KIND_BOX) {
+            std::memcpy(d.c, ho.pos, 12);
+            for (int k = 0; k < 3; ++k) d.half[k] = ho.size[k] * 0.5f;                     // Box.cpp:30
+            d.eps = 1e-4f * std::max(std::max(d.half[0], d.half[1]), d.half[2]);          // Box.cpp:63
+            Mat4 R = rotate_euler_xyz(Mat4::identity(), ho.rot);                          // Box.cpp:16-19
+            for (int k = 0; k < 3; ++k) { d.ax0[k] = R.m[0][k]; d.ax1[k] = R.m[1][k]; d.ax2[k] = R.m[2][k]; }
+            d.material = (int32_t)materials.size(); materials.push_back(to_dmaterial(ho.mat));
+        } else {
+            HostMesh& hm = *ho.mesh;
+            const Model& md = hm.model;
+            if (!hm.bvh_valid) {
+                hm.bvh = build_bvh(md.positions.data(), md.num_faces(), maxDepth);
+                hm.bvh_valid = true;
+                if (hm.bvh.depth > maxDepth) return fail(PTAMD_ERR_LIMIT, "BVH deeper than the traversal stack");
+            }
+            size_t slot = 0;
+            for (; slot < uploaded.size(); ++slot) if (uploaded[slot].first == &hm) break;
+            if (slot == uploaded.size()) {
+                MeshSlots ms;
+                ms.node_base = (uint32_t)nodes.size(); ms.tri_base = (uint32_t)tris.size();
+                ms.group_base = (uint32_t)groups.size(); ms.image_base = (uint32_t)images.size(); ms.flags = 0;
+                nodes.insert(nodes.end(), hm.bvh.nodes.begin(), hm.bvh.nodes.end());
+                for (uint32_t i = 0; i < md.num_faces(); ++i) {
+                    uint32_t f = hm.bvh.order[i];
+                    const float* p = &md.positions[9 * (size_t)f];
+                    DTri t; std::memset(&t, 0, sizeof t);
+                    t.v0[0] = p[0]; t.v0[1] = p[1]; t.v0[2] = p[2];
+                    t.e1x = p[3] - p[0]; t.e1yz[0] = p[4] - p[1]; t.e1yz[1] = p[5] - p[2];
+                    t.e2xy[0] = p[6] - p[0]; t.e2xy[1] = p[7] - p[1]; t.e2z = p[8] - p[2];
+                    t.group = md.group[f];
+                    tris.push_back(t);
+                    DShade sh; std::memset(&sh, 0, sizeof sh);
+                    std::memcpy(sh.pa, p, 36);
+                    std::memcpy(sh.na, &md.normals[9 * (size_t)f], 36);
+                    std::memcpy(sh.ta, &md.texcoords[6 * (size_t)f], 24);
+                    sh.group = md.group[f];
+                    shade.push_back(sh);
+                }
+                for (size_t i = 0; i < md.images.size(); ++i) {
+                    DImage di; di.width = md.images[i].width; di.height = md.images[i].height; di.offset = (uint32_t)texels.size(); di.pad = 0;
+                    texels.insert(texels.end(), md.image_data[i].begin(), md.image_data[i].end());
+                    images.push_back(di);
+                }
+                for (const ptamd_pbr& g : md.groups) {
+                    DPbr dg; std::memset(&dg, 0, sizeof dg);
+                    auto img = [&](int32_t t) { return t >= 0 ? (int32_t)(ms.image_base + (uint32_t)t) : -1; };
+                    dg.base_color_tex = img(g.base_color_tex); dg.normal_tex = img(g.normal_tex);
+                    dg.metallic_roughness_tex = img(g.metallic_roughness_tex); dg.emissive_tex = img(g.emissive_tex);
+                    dg.transmission_tex = img(g.transmission_tex);
+                    dg.alpha_mode = g.alpha_mode; dg.alpha_cutoff = g.alpha_cutoff; dg.normal_scale = g.normal_scale;
+                    std::memcpy(dg.base_color_factor, g.base_color_factor, 16);
+                    std::memcpy(dg.emissive_factor, g.emissive_factor, 12);
+                    dg.metallic_factor = g.metallic_factor; dg.roughness_factor = g.roughness_factor;
+                    dg.transmission_factor = g.transmission_factor; dg.ior = g.ior;
+                    dg.material = (int32_t)materials.size();
+                    materials.push_back(to_dmaterial(group_material(g)));
+                    if (g.alpha_mode == 1) ms.flags |= 1u;
+                    if (g.base_color_tex >= 0 || g.normal_tex >= 0 || g.metallic_roughness_tex >= 0 || g.emissive_tex >= 0 || g.transmission_tex >= 0) ms.flags |= 2u;
+                    groups.push_back(dg);
+                }
+                uploaded.emplace_back(&hm, (uint32_t)slots.size());
+                slots.push_back(ms);
+            }
+            const MeshSlots& ms = slots[uploaded[slot].second];
+            DMesh dm; std::memset(&dm, 0, sizeof dm);
+            Mat4 M = translate(Mat4::identity(), ho.pos);                                  // Mesh.cpp:47-52
+            M = rotate_euler_xyz(M, ho.rot);
+            M = scale(M, ho.size);
+            Mat4 Minv = inverse(M);                                                        // Mesh.cpp:54
+            rows3x4(M, dm.m); rows3x4(Minv, dm.minv);
+            dm.node_base = ms.node_base; dm.tri_base = ms.tri_base; dm.group_base = ms.group_base; dm.image_base = ms.image_base;
+            dm.num_tris = md.num_faces(); dm.root = hm.bvh.root; dm.flags = ms.flags;
+            d.mesh = (int32_t)meshes.size();
+            meshes.push_back(dm);
+        }
+        objects.push_back(d);
+    }
+
+    s->release();
+    if (int rc = s->d_objects.upload(objects)) return rc;
+    if (int rc = s->d_meshes.upload(meshes)) return rc;
+    if (int rc = s->d_materials.upload(materials)) return rc;
+    if (int rc = s->d_nodes.upload(nodes)) return rc;
+    if (int rc = s->d_tris.upload(tris)) return rc;
+    if (int rc = s->d_shade.upload(shade)) return rc;
+    if (int rc = s->d_groups.upload(groups)) return rc;
+    if (int rc = s->d_images.upload(images)) return rc;
+    if (int rc = s->d_texels.upload(texels)) return rc;
+    DScene& ds = s->dscene;
+    ds.objects = s->d_objects.ptr; ds.num_objects = (int32_t)objects.size(); ds.max_stack = maxDepth;
+    ds.meshes = s->d_meshes.ptr; ds.materials = s->d_materials.ptr;
+    ds.nodes = reinterpret_cast<const float4*>(s->d_nodes.ptr);
+    ds.tris = reinterpret_cast<const float4*>(s->d_tris.ptr);
+    ds.shade = reinterpret_cast<const float4*>(s->d_shade.ptr);
+    ds.groups = s->d_groups.ptr; ds.images = s->d_images.ptr; ds.texels = s->d_texels.ptr;
+    std::memcpy(ds.background, s->background, 12);
+    s->committed = true;
+    return PTAMD_OK;
+}
+
+// ------------------------------------------------------------------------------- model
+int ptamd_model_load(const char* path, ptamd_model** out)
+{
+    if (!path || !out) return fail(PTAMD_ERR_ARG, "null argument");
+    auto m = std::make_unique<ptamd_model>();
+    try {
+        load_gltf(path, m->model);
+    } catch (const std::exception& e) {
+        return fail(PTAMD_ERR_IO, e.what());
+    }
+    *out = m.release();
+    return PTAMD_OK;
+}
+int ptamd_model_desc(const ptamd_model* m, ptamd_mesh_desc* out)
+{
+    if (!m || !out) return fail(PTAMD_ERR_ARG, "null argument");
+    const Model& md = m->model;
+    out->num_faces = md.num_faces();
+    out->positions = md.positions.data(); out->normals = md.normals.data(); out->texcoords = md.texcoords.data();
+    out->group = md.group.data();
+    out->num_groups = (uint32_t)md.groups.size(); out->groups = md.groups.data();
+    out->num_images = (uint32_t)md.images.size(); out->images = md.images.data();
+    return PTAMD_OK;
+}
+const char* ptamd_model_group_name(const ptamd_model* m, uint32_t group)
+{
+    if (!m || group >= m->model.group_names.size()) return nullptr;
+    return m->model.group_names[group].c_str();
+}
+void ptamd_model_free(ptamd_model* m) { delete m; }
+
+// ------------------------------------------------------------------------------- film
+static int film_alloc(ptamd_film* f, int w, int h)
+{
+    f->w = std::max(0, w); f->h = std::max(0, h); // Film::Resize clamps at 0 (Film.cpp:18-19)
+    size_t n = std::max<size_t>(1, (size_t)f->w * f->h);
+    PT_HIP(hipMalloc(reinterpret_cast<void**>(&f->accum), n * 12));
+    PT_HIP(hipMalloc(reinterpret_cast<void**>(&f->samples), n * 4));
+    PT_HIP(hipMemsetAsync(f->accum, 0, n * 12, g_stream));
+    PT_HIP(hipMemsetAsync(f->samples, 0, n * 4, g_stream));
+    return PTAMD_OK;
+}
+int ptamd_film_create(int w, int h, ptamd_film** out)
+{
+    if (!out) return fail(PTAMD_ERR_ARG, "null output pointer");
+    if (int rc = need_init()) return rc;
+    auto f = std::make_unique<ptamd_film>();
+    if (int rc = film_alloc(f.get(), w, h)) { f->release(); return rc; }
+    *out = f.release();
+    return PTAMD_OK;
+}
+int ptamd_film_create_external(int w, int h, float* d_accum, uint32_t* d_samples, ptamd_film** out)
+{
+    if (!out || !d_accum || !d_samples || w <= 0 || h <= 0) return fail(PTAMD_ERR_ARG, "bad external film arguments");
+    if (int rc = need_init()) return rc;
+    auto f = new ptamd_film();
+    f->w = w; f->h = h; f->accum = d_accum; f->samples = d_samples; f->external = true;
+    *out = f;
+    return PTAMD_OK;
+}
+int ptamd_film_destroy(ptamd_film* f)
+{
+    if (!f) return PTAMD_OK;
+    if (g_initialised) (void)hipStreamSynchronize(g_stream);
+    f->release();
+    delete f;
+    return PTAMD_OK;
+}
+int ptamd_film_resize(ptamd_film* f, int w, int h)
+{
+    if (!f) return fail(PTAMD_ERR_ARG, "null film handle");
+    if (f->external) return fail(PTAMD_ERR_STATE, "a film over caller-owned buffers cannot be resized");
+    if (int rc = need_init()) return rc;
+    PT_HIP(hipStreamSynchronize(g_stream));
+    f->release();
+    return film_alloc(f, w, h);
+}
+int ptamd_film_reset(ptamd_film* f)
+{
+    if (!f) return fail(PTAMD_ERR_ARG, "null film handle");
+    if (int rc = need_init()) return rc;
+    size_t n = (size_t)f->w * f->h;
+    if (n) { PT_HIP(hipMemsetAsync(f->accum, 0, n * 12, g_stream)); PT_HIP(hipMemsetAsync(f->samples, 0, n * 4, g_stream)); }
+    return PTAMD_OK;
+}
+int ptamd_film_size(const ptamd_film* f, int* w, int* h)
+{
+    if (!f) return fail(PTAMD_ERR_ARG, "null film handle");
+    if (w) *w = f->w;
+    if (h) *h = f->h;
+    return PTAMD_OK;
+}
+int ptamd_film_read(ptamd_film* f, float* accum, uint32_t* samples)
+{
+    if (!f) return fail(PTAMD_ERR_ARG, "null film handle");
+    if (int rc = need_init()) return rc;
+    size_t n = (size_t)f->w * f->h;
+    if (accum && n) PT_HIP(hipMemcpyAsync(accum, f->accum, n * 12, hipMemcpyDeviceToHost, g_stream));
+    if (samples && n) PT_HIP(hipMemcpyAsync(samples, f->samples, n * 4, hipMemcpyDeviceToHost, g_stream));
+    PT_HIP(hipStreamSynchronize(g_stream));
+    return PTAMD_OK;
+}
+int ptamd_film_average(ptamd_film* f, float* avg)
+{
+    if (!f || !avg) return fail(PTAMD_ERR_ARG, "null argument");
+    if (int rc = need_init()) return rc;
+    size_t n = (size_t)f->w * f->h;
+    if (!n) return PTAMD_OK;
+    if (!f->avg) PT_HIP(hipMalloc(reinterpret_cast<void**>(&f->avg), n * 12));
+    PT_HIP(launch_average(f->accum, f->samples, (int)n, f->avg, g_stream));
+    PT_HIP(hipMemcpyAsync(avg, f->avg, n * 12, hipMemcpyDeviceToHost, g_stream));
+    PT_HIP(hipStreamSynchronize(g_stream));
+    return PTAMD_OK;
+}
+int ptamd_film_resolve_rgba8(ptamd_film* f, int tonemap, int colourspace, uint8_t* rgba)
+{
+    if (!f || !rgba) return fail(PTAMD_ERR_ARG, "null argument");
+    if (tonemap < 0 || tonemap > 1 || colourspace < 0 || colourspace > 1) return fail(PTAMD_ERR_ARG, "tonemap / colourspace must be 0 or 1");
+    if (int rc = need_init()) return rc;
+    size_t n = (size_t)f->w * f->h;
+    if (!n) return PTAMD_OK;
+    if (!f->rgba) PT_HIP(hipMalloc(reinterpret_cast<void**>(&f->rgba), n * 4));
+    PT_HIP(launch_resolve(f->accum, f->samples, (int)n, tonemap, colourspace, f->rgba, g_stream));
+    PT_HIP(hipMemcpyAsync(rgba, f->rgba, n * 4, hipMemcpyDeviceToHost, g_stream));
+    PT_HIP(hipStreamSynchronize(g_stream));
+    return PTAMD_OK;
+}
+int ptamd_film_device_ptrs(ptamd_film* f, void** a, void** s)
+{
+    if (!f) return fail(PTAMD_ERR_ARG, "null film handle");
+    if (a) *a = f->accum;
+    if (s) *s = f->samples;
+    return PTAMD_OK;
+}
+
+// ------------------------------------------------------------------------------- render
+int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
+                 int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags)
+{
+    if (!s || !cam || !f) return fail(PTAMD_ERR_ARG, "null argument");
+    if (int rc = need_init()) return rc;
+    if (!s->committed) return fail(PTAMD_ERR_STATE, "scene has uncommitted edits: call ptamd_scene_commit first");
+    if (f->w <= 0 || f->h <= 0) return fail(PTAMD_ERR_STATE, "film has no pixels");
+    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(PTAMD_ERR_ARG, "sample index range overflows 32 bits");
+    DRenderParams rp; std::memset(&rp, 0, sizeof rp);
+    rp.cam = make_camera(*cam, f->w, f->h);
+    rp.accum = f->accum; rp.samples = f->samples;
+    rp.x0 = rect ? std::max(0, rect->x0) : 0; rp.y0 = rect ? std::max(0, rect->y0) : 0;
+    rp.x1 = rect ? std::min(f->w, rect->x1) : f->w; rp.y1 = rect ? std::min(f->h, rect->y1) : f->h;
+    if (flags & PTAMD_FLAG_COUNT) {
+        PT_HIP(hipMemsetAsync(g_counters, 0, 2 * sizeof(unsigned long long), g_stream));
+        rp.counters = g_counters;
+    }
+    if (rp.x1 <= rp.x0 || rp.y1 <= rp.y0 || spp_count == 0) return PTAMD_OK;
+    rp.spp_begin = spp_begin; rp.spp_count = spp_count;
+    rp.depth = depth; rp.albedo_only = albedo_only ? 1 : 0; rp.seed = seed; rp.flags = flags;
+    rp.tiles_x = (rp.x1 - rp.x0 + 7) / 8; rp.tiles_y = (rp.y1 - rp.y0 + 7) / 8;
+    if (depth <= 0) {
+        // TraceRay returns 0 at once (PathTracer.cpp:35-36): every sample adds black
+        rp.depth = 0;
+    }
+    PT_HIP(launch_render(s->dscene, rp, g_stream));
+    return PTAMD_OK;
+}
+int ptamd_render_stats(ptamd_stats* out)
+{
+    if (!out) return fail(PTAMD_ERR_ARG, "null argument");
+    if (int rc = need_init()) return rc;
+    unsigned long long c[2];
+    PT_HIP(hipMemcpyAsync(c, g_counters, sizeof c, hipMemcpyDeviceToHost, g_stream));
+    PT_HIP(hipStreamSynchronize(g_stream));
+    out->samples = c[0]; out->rays = c[1];
+    return PTAMD_OK;
+}
+
+// ------------------------------------------------------------------------------- probes
+int ptamd_camera_rays(const ptamd_camera* cam, int w, int h, float* out)
+{
+    if (!cam || !out || w <= 0 || h <= 0) return fail(PTAMD_ERR_ARG, "bad argument");
+    if (int rc = need_init()) return rc;
+    DCamera dc = make_camera(*cam, w, h);
+    float* d = nullptr;
+    size_t bytes = (size_t)w * h * 6 * sizeof(float);
+    PT_HIP(hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    hipError_t e = launch_camera_rays(dc, d, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    (void)hipFree(d);
+    PT_HIP(e);
+    return PTAMD_OK;
+}
+int ptamd_closest_hits(ptamd_scene* s, const float* rays, uint32_t n, float* rec)
+{
+    if (!s || !rays || !rec) return fail(PTAMD_ERR_ARG, "null argument");
+    if (int rc = need_init()) return rc;
+    if (!s->committed) return fail(PTAMD_ERR_STATE, "scene has uncommitted edits: call ptamd_scene_commit first");
+    if (n == 0) return PTAMD_OK;
+    float *d_rays = nullptr, *d_rec = nullptr;
+    PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_rec), (size_t)n * 80);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess) e = launch_closest_hits(s->dscene, d_rays, n, d_rec, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(rec, d_rec, (size_t)n * 80, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    (void)hipFree(d_rays); (void)hipFree(d_rec);
+    PT_HIP(e);
+    return PTAMD_OK;
+}
+
+} // extern "C"

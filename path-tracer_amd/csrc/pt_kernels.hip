@@ -1,0 +1,212 @@
+// HIP kernels of the path-tracing core (gfx950 / CDNA4, wave64).
+//
+// render_kernel: one lane per pixel, one wave per 8x8-pixel tile. Each lane runs every sample of its
+// pixel for this launch with *path regeneration*: the loop body is one ray segment (closest hit +
+// shade); a lane whose path ends adds the sample to its register accumulator and immediately starts
+// the next sample, so lanes stay busy although path lengths differ. The film is read once and
+// written once per launch (16 B per pixel), in the reference's sample order.
+#include <hip/hip_runtime.h>
+#include "pt_device.h"
+
+namespace ptamd {
+
+constexpr int kBlock = 256;      // 4 waves, each owning one 8x8 tile
+constexpr int kStackDepth = 32;  // per-lane traversal stack entries held in LDS
+
+// Film::AddSample (Film.cpp:34-46) on a register accumulator.
+PT_DEV void add_sample(f3& acc, f3 c)
+{
+    float lum = dot(c, mk3(0.2126f, 0.7152f, 0.0722f));
+    if (lum > 12.0f) c = c * (12.0f / lum);
+    acc = acc + c;
+}
+
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DRenderParams rp)
+{
+    __shared__ uint32_t stack[STACK * kBlock];
+    const int slot = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int tx = tile % rp.tiles_x, ty = tile / rp.tiles_x;
+    const int px = rp.x0 + tx * 8 + (lane & 7), py = rp.y0 + ty * 8 + (lane >> 3);
+    const bool inside = (ty < rp.tiles_y) && (px < rp.x1) && (py < rp.y1);
+    const int W = rp.cam.width;
+    const uint32_t pixel = (uint32_t)(py * W + px);
+
+    // depth <= 0: TraceRay returns black at once (PathTracer.cpp:35-36); the samples are still counted.
+    uint32_t s = rp.spp_begin;
+    const uint32_t s_end = (inside && rp.depth > 0) ? rp.spp_begin + rp.spp_count : rp.spp_begin;
+    const uint32_t seed_hash = pcg_hash(rp.seed);
+
+    Ray primary = camera_ray(rp.cam, px, py);
+    f3 acc = mk3(0.f, 0.f, 0.f);
+    if (inside) acc = mk3(rp.accum[3 * (size_t)pixel], rp.accum[3 * (size_t)pixel + 1], rp.accum[3 * (size_t)pixel + 2]);
+
+    // path state
+    Ray ray = primary;
+    float ior = 1.0f;
+    f3 T = mk3(1.f, 1.f, 1.f), L = mk3(0.f, 0.f, 0.f);
+    int bounce = 0;
+    uint32_t key = path_key(seed_hash, pixel, s);
+    uint32_t nrays = 0;
+    const f3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
+
+    while (s < s_end) {
+        ++nrays;
+        Best best = closest_hit<kBlock>(sc, ray, stack, slot);
+        bool done;
+        if (best.obj < 0) {
+            L = L + T * bg;                       // PathTracer.cpp:59-60
+            done = true;
+        } else {
+            HitInfo h;
+            fill_hit(sc, ray, best, h);
+            if (rp.albedo_only && bounce == 0) {  // PathTracer.cpp:62-71 (recursive calls never pass albedoOnly)
+                float dist = clampf(best.t / 20.f, 0.0f, 0.8f);
+                L = h.albedo * (1.0f - dist);
+                done = true;
+            } else {
+                L = L + T * h.emission;           // PathTracer.cpp:76
+                if (bounce + 1 >= rp.depth) {
+                    done = true;                  // the next TraceRay would return 0 (PathTracer.cpp:35-36)
+                } else {
+                    f3 w;
+                    done = !sample_bsdf(h, ray, ior, w, key, (uint32_t)bounce);
+                    T = T * w;
+                    ++bounce;
+                }
+            }
+        }
+        if (done) {
+            add_sample(acc, L);
+            ++s;
+            ray = primary; ior = 1.0f;
+            T = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f);
+            bounce = 0;
+            key = path_key(seed_hash, pixel, s);
+        }
+    }
+
+    if (inside) {
+        rp.accum[3 * (size_t)pixel] = acc.x; rp.accum[3 * (size_t)pixel + 1] = acc.y; rp.accum[3 * (size_t)pixel + 2] = acc.z;
+        rp.samples[pixel] += rp.spp_count;
+    }
+    if (rp.counters) {
+        // wave-level reduction, then one atomic per wave
+        unsigned long long r = nrays, n = inside ? rp.spp_count : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            r += __shfl_xor(r, off, 64);
+            n += __shfl_xor(n, off, 64);
+        }
+        if (lane == 0) { atomicAdd(&rp.counters[0], n); atomicAdd(&rp.counters[1], r); }
+    }
+}
+
+// Camera::GetRay probe.
+__global__ void camera_rays_kernel(DCamera cam, float* out)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= cam.width || y >= cam.height) return;
+    Ray r = camera_ray(cam, x, y);
+    float* o = out + ((size_t)y * cam.width + x) * 6;
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+}
+
+// Closest-hit probe: 20 floats per ray {hit, t, p, n, frontFace, material(11)}.
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void closest_hits_kernel(DScene sc, const float* rays, uint32_t n, float* rec)
+{
+    __shared__ uint32_t stack[STACK * kBlock];
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Ray ray;
+    ray.o = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    ray.d = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    Best best = closest_hit<kBlock>(sc, ray, stack, (int)threadIdx.x);
+    float* o = rec + (size_t)i * 20;
+    for (int k = 0; k < 20; ++k) o[k] = 0.f;
+    if (best.obj < 0) return;
+    HitInfo h;
+    fill_hit(sc, ray, best, h);
+    // raw material fields (emission is reported as colour/strength of the table entry when there is one)
+    o[0] = 1.f; o[1] = best.t; o[2] = h.p.x; o[3] = h.p.y; o[4] = h.p.z; o[5] = h.n.x; o[6] = h.n.y; o[7] = h.n.z;
+    o[8] = h.frontFace ? 1.f : 0.f;
+    o[9] = h.albedo.x; o[10] = h.albedo.y; o[11] = h.albedo.z; o[12] = h.roughness; o[13] = h.metallic;
+    o[14] = h.emission.x; o[15] = h.emission.y; o[16] = h.emission.z; // colour * strength
+    o[17] = 1.f; o[18] = h.ior; o[19] = h.transmission;
+}
+
+// Film::AverageAt (Film.cpp:48-53) for every pixel.
+__global__ void average_kernel(const float* accum, const uint32_t* samples, int n, float* avg)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t s = samples[p];
+    float fs = (float)s;
+    avg[3 * p] = s ? accum[3 * p] / fs : 0.f;
+    avg[3 * p + 1] = s ? accum[3 * p + 1] / fs : 0.f;
+    avg[3 * p + 2] = s ? accum[3 * p + 2] / fs : 0.f;
+}
+
+PT_DEV float srgb_oetf(float c)
+{
+    float u = fmaxf(0.0f, c);
+    return (u <= 0.0031308f) ? (12.92f * u) : (1.055f * powf(u, 1.0f / 2.4f) - 0.055f);
+}
+// Film::ResolveToRGBA8 (Film.cpp:55-104): 16 B in, 4 B out per pixel.
+__global__ void resolve_kernel(const float* accum, const uint32_t* samples, int n, int tonemap, int colourspace, uint32_t* rgba)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t s = samples[p];
+    float fs = (float)s;
+    float c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = s ? accum[3 * p + k] / fs : 0.f;
+        if (tonemap == 1) v = v / (1.0f + v);
+        if (colourspace == 1) v = srgb_oetf(v);
+        c[k] = clampf(v, 0.0f, 1.0f);
+    }
+    uint32_t r = (uint32_t)lroundf(c[0] * 255.0f), g = (uint32_t)lroundf(c[1] * 255.0f), b = (uint32_t)lroundf(c[2] * 255.0f);
+    rgba[p] = r | (g << 8) | (b << 16) | (255u << 24);
+}
+
+// ---------------------------------------------------------------- launchers (called from pt_host.cpp)
+hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t stream)
+{
+    int tiles = rp.tiles_x * rp.tiles_y;
+    int blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(render_kernel<kStackDepth>, dim3(blocks), dim3(kBlock), 0, stream, sc, rp);
+    return hipGetLastError();
+}
+hipError_t launch_camera_rays(const DCamera& cam, float* d_out, hipStream_t stream)
+{
+    dim3 grid((cam.width + 63) / 64, cam.height);
+    hipLaunchKernelGGL(camera_rays_kernel, grid, dim3(64), 0, stream, cam, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_closest_hits(const DScene& sc, const float* d_rays, uint32_t n, float* d_rec, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(closest_hits_kernel<kStackDepth>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, d_rays, n, d_rec);
+    return hipGetLastError();
+}
+hipError_t launch_average(const float* accum, const uint32_t* samples, int n, float* avg, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(average_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, accum, samples, n, avg);
+    return hipGetLastError();
+}
+hipError_t launch_resolve(const float* accum, const uint32_t* samples, int n, int tonemap, int colourspace, uint32_t* rgba, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, accum, samples, n, tonemap, colourspace, rgba);
+    return hipGetLastError();
+}
+int max_stack_depth() { return kStackDepth; }
+
+} // namespace ptamd

@@ -1,0 +1,119 @@
+// Device-side data layout shared by the host flattening code and the HIP kernels.
+//
+// Everything the kernels read is one of:
+//   * a wave-uniform table (objects, mesh instances, materials, PBR groups): read through scalar
+//     loads, a few hundred bytes per scene;
+//   * per-mesh BVH nodes (64 B, both child boxes in the parent) and hot triangles (48 B: v0,e1,e2),
+//     stored as float4 so that every per-lane fetch is a 16-byte load;
+//   * cold per-triangle shading records (112 B) touched once per ray at the closest hit;
+//   * the film (12 B accum + 4 B count per pixel), read and written once per launch.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+namespace ptamd {
+
+enum : int { KIND_SPHERE = 0, KIND_BOX = 1, KIND_MESH = 2 };
+
+// RayObject.h:10-20 plus padding to 3 x float4.
+struct DMaterial {
+    float albedo[3]; float roughness;
+    float metallic; float emission_colour[3];
+    float emission_strength; float ior; float transmission; float pad;
+};
+
+// One entry per RayObject, in AddRayObject order (the closest-hit loop keeps the first of equal hits).
+struct DObject {
+    int32_t kind, material, mesh, pad0;
+    float c[3]; float radius;       // sphere/box centre; sphere radius
+    float half[3]; float eps;       // box half extents; face epsilon = 1e-4 * max half extent (Box.cpp:63)
+    float ax0[3]; float pad1;       // box axes = columns of worldFromLocal (Box.cpp:16-23)
+    float ax1[3]; float pad2;
+    float ax2[3]; float pad3;
+};
+
+// Mesh instance (Mesh.cpp:47-55), rows of the affine 3x4 parts so a point transform is 3 dot products.
+struct DMesh {
+    float minv[12];   // minv[4*r + c] = Minv[c][r] (glm column-major), r = 0..2, c = 0..3
+    float m[12];      // same for M
+    uint32_t node_base;   // index of this mesh's root node in the node array (in 64-B nodes)
+    uint32_t tri_base;    // index of its first hot triangle (in 48-B records)
+    uint32_t group_base;  // index of its first PBR group
+    uint32_t image_base;  // index of its first image
+    uint32_t num_tris;
+    int32_t root;         // child reference of the root (see DNode)
+    uint32_t flags;       // bit 0: some group uses alpha MASK; bit 1: some group samples a texture
+    uint32_t pad;
+};
+
+// BVH2 node holding both children's boxes. Child reference: >= 0 -> node index (relative to node_base);
+// < 0 -> leaf: ~ref = (first_triangle << 3) | (count - 1), triangles relative to tri_base.
+struct DNode {
+    float lmin[3]; float lmax0;     // f4 0: l.min.xyz, l.max.x
+    float lmax12[2]; float rmin01[2]; // f4 1: l.max.yz, r.min.xy
+    float rmin2; float rmax[3];     // f4 2: r.min.z, r.max.xyz
+    int32_t left, right; int32_t pad[2]; // f4 3
+};
+
+// Hot triangle: v0, e1 = v1 - v0, e2 = v2 - v0 (the values Mesh::RayTriMT recomputes per test, Mesh.cpp:421-426).
+struct DTri {
+    float v0[3]; float e1x;
+    float e1yz[2]; float e2xy[2];
+    float e2z; int32_t group; int32_t pad[2];
+};
+
+// Cold shading record in the same (leaf) order as DTri: ModelLoader::Face (ModelLoader.h:29-40).
+struct DShade {
+    float pa[3], pb[3], pc[3];
+    float na[3], nb[3], nc[3];
+    float ta[2], tb[2], tc[2];
+    int32_t group;
+    float pad[3];
+};
+static_assert(sizeof(DShade) == 112, "DShade is 7 float4");
+
+// ModelLoader::PBRMaterial (ModelLoader.h:56-85), device form; image indices are global.
+struct DPbr {
+    int32_t base_color_tex, normal_tex, metallic_roughness_tex, emissive_tex;
+    int32_t transmission_tex, alpha_mode; float alpha_cutoff, normal_scale;
+    float base_color_factor[4];
+    float emissive_factor[3]; float metallic_factor;
+    float roughness_factor, transmission_factor, ior; int32_t material; // slot of the constant material when no texture is sampled
+};
+
+// ModelLoader::EmbeddedImage: texels always RGBA8 in one arena.
+struct DImage { int32_t width, height; uint32_t offset; uint32_t pad; };
+
+struct DScene {
+    const DObject* objects; int32_t num_objects; int32_t max_stack;
+    const DMesh* meshes;
+    const DMaterial* materials;
+    const float4* nodes;   // DNode as 4 float4
+    const float4* tris;    // DTri as 3 float4
+    const float4* shade;   // DShade as 7 float4
+    const DPbr* groups;
+    const DImage* images;
+    const uint8_t* texels;
+    float background[3]; int32_t pad;
+};
+
+// Camera matrices as Camera::CalculateMatrices leaves them (Camera.cpp:22-35), glm column-major.
+struct DCamera {
+    float inv_proj[16];
+    float inv_view[16];
+    int32_t width, height, pad0, pad1;
+};
+
+struct DRenderParams {
+    DCamera cam;
+    float* accum;          // w*h*3
+    uint32_t* samples;     // w*h
+    unsigned long long* counters; // [0] samples, [1] rays, or null
+    int32_t x0, y0, x1, y1;
+    uint32_t spp_begin, spp_count;
+    int32_t depth, albedo_only;
+    uint32_t seed, flags;
+    int32_t tiles_x, tiles_y; // 8x8-pixel tiles covering the rect
+};
+
+} // namespace ptamd

@@ -1,0 +1,86 @@
+"""Generates the golden fixtures in this directory from the reference renderer's own sources
+(oracle/_ref/ref_oracle, built by `make -C oracle ref`; only possible where /root/reference exists).
+
+Run:  python tests/golden/make_golden.py
+Writes small .npz files (inputs + expected outputs) and the .glb inputs the reference loaded.
+Nothing of the reference's source text is stored: only scene parameters and output buffers.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po  # noqa: E402
+from scenes import gltf_io, presets  # noqa: E402
+
+
+def lum(a):
+    return (a * np.array([0.2126, 0.7152, 0.0722], np.float32)).sum(-1)
+
+
+def golden_scenes():
+    """name -> (scene dict, depth for the stochastic render)."""
+    cm = os.path.join(HERE, "cornell_mesh.glb")
+    blob = os.path.join(HERE, "blob.glb")
+    gltf_io.write_box_scene_glb(cm, presets.box_cornell()["objects"])
+    # a smooth procedural mesh with two materials (one glass, one rough metal) and vertex normals
+    p0 = gltf_io.bumpy_sphere_primitive(48, 64, radius=1.0, material_index=0)
+    p1 = gltf_io.bumpy_sphere_primitive(24, 32, radius=0.45, bump=0.15, freq=5, material_index=1)
+    p1["positions"] = p1["positions"] + np.array([1.3, 0.9, -0.2], np.float32)
+    mats = [gltf_io.gltf_material("copper", presets.material(albedo=(0.9, 0.5, 0.3), roughness=0.3, metallic=1.0)),
+            gltf_io.gltf_material("glass", presets.material(albedo=(1, 1, 1), roughness=0.0, ior=1.45, transmission=1.0))]
+    gltf_io.write_glb(blob, [p0, p1], mats)
+    blob_scene = presets.mixed("tests/golden/blob.glb", 96, 96, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
+    return {
+        "sphere_cornell": (presets.sphere_cornell(96, 96), 5),
+        "glass_mirror": (presets.glass_mirror(96, 96), 12),
+        "box_cornell": (presets.box_cornell(96, 64), 6),
+        "mesh_cornell": (presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 54), 8),
+        "blob_mixed": (blob_scene, 8),
+    }
+
+
+def main():
+    assert po.have_ref(), "build oracle/_ref first: make -C oracle ref"
+    os.chdir(ROOT)  # mesh paths in the scenes are relative to the repo root
+    for name, (scene, depth) in golden_scenes().items():
+        rays = po.ref_rays(scene)
+        hits = po.ref_hits(scene)
+        alb, alb_s, alb_rgba, _ = po.ref_render(scene, 1, 10, True, threads=4, tasks=16)
+        d1, d1_s, _, _ = po.ref_render(scene, 2, 1, False, threads=4, tasks=16)
+        spp = 256
+        a1, s1, rgba1, _ = po.ref_render(scene, spp, depth, False)
+        a2, s2, _, _ = po.ref_render(scene, spp, depth, False)
+        A1, A2 = po.average(a1, s1), po.average(a2, s2)
+        self_rmse = float(np.sqrt(((A1 - A2) ** 2).mean()))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rays=rays, hits=hits, albedo_accum=alb,
+                            albedo_rgba=alb_rgba, depth1_accum=d1, depth1_samples=d1_s,
+                            avg_a=A1.astype(np.float16), avg_b=A2.astype(np.float16), spp=spp, depth=depth,
+                            self_rmse=self_rmse, mean_lum_a=float(lum(A1).mean()), mean_lum_b=float(lum(A2).mean()),
+                            rgba_a=rgba1)
+        print(name, "self_rmse", self_rmse, "lum", float(lum(A1).mean()), float(lum(A2).mean()))
+    # Film known-answer vectors: AddSample clamp + the four resolve variants
+    rng = np.random.default_rng(7)
+    vals = np.concatenate([rng.random((200, 3)) * np.array([0.02, 1.0, 30.0])[rng.integers(0, 3, (200, 1))],
+                           np.array([[0, 0, 0], [12, 12, 12], [15, 12.6, 8.85], [0.0031308, 0.0031307, 0.0031309],
+                                     [1e-8, 1e3, 0.5], [100, 0, 0], [0, 100, 0], [0, 0, 100]])]).astype(np.float32)
+    import tempfile
+    d = tempfile.mkdtemp()
+    vals.tofile(os.path.join(d, "in.f32"))
+    import subprocess
+    subprocess.run([po.REF_BIN, "film", os.path.join(d, "in.f32"), str(len(vals)), os.path.join(d, "out")], check=True)
+    out = {"values": vals, "accum": np.fromfile(os.path.join(d, "out.accum.f32"), np.float32).reshape(-1, 3),
+           "samples": np.fromfile(os.path.join(d, "out.samples.u32"), np.uint32),
+           "avg": np.fromfile(os.path.join(d, "out.avg.f32"), np.float32).reshape(-1, 3)}
+    for cs in (0, 1):
+        for tm in (0, 1):
+            out["rgba_cs%d_tm%d" % (cs, tm)] = np.fromfile(os.path.join(d, "out.cs%d.tm%d.rgba8" % (cs, tm)), np.uint8).reshape(-1, 4)
+    np.savez_compressed(os.path.join(HERE, "film_kat.npz"), **out)
+    print("film_kat", len(vals))
+
+
+if __name__ == "__main__":
+    main()
