@@ -176,6 +176,10 @@ int ptamd_camera_rays(const ptamd_camera* cam, int width, int height, float* out
 /* Closest-hit loop of PathTracer::TraceRay (PathTracer.cpp:38-57) for n host rays (6 floats each);
  * rec: n*20 floats {hit, t, p xyz, n xyz, frontFace, material 11 floats}. */
 int ptamd_closest_hits(ptamd_scene* s, const float* rays, uint32_t n, float* rec);
+/* The same, plus the work the GPU traversal did per ray: counts[2*i] = BVH nodes visited (each tests two child
+ * boxes), counts[2*i+1] = ray-triangle tests. No reference counterpart; used to report executed next to
+ * algorithmic work. */
+int ptamd_traversal_counts(ptamd_scene* s, const float* rays, uint32_t n, float* rec, uint32_t* counts);
 
 #ifdef __cplusplus
 }

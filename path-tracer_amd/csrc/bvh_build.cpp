@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -22,8 +23,8 @@ struct Box3 {
 };
 
 constexpr int kBins = 16;
-constexpr uint32_t kLeafMax = 4;
-constexpr float kCostNode = 1.0f, kCostTri = 1.2f;
+uint32_t kLeafMax = 4;
+float kCostNode = 1.0f, kCostTri = 1.2f;
 
 struct Builder {
     std::vector<Box3> fb;
@@ -129,6 +130,8 @@ struct Builder {
 BvhResult build_bvh(const float* P, uint32_t n, int max_depth)
 {
     BvhResult res;
+    if (const char* e = std::getenv("PTAMD_LEAF_MAX")) kLeafMax = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
+    if (const char* e = std::getenv("PTAMD_COST_TRI")) kCostTri = (float)std::atof(e);
     Builder b;
     b.maxDepth = max_depth;
     b.fb.resize(n); b.fc.resize(3 * (size_t)n); b.idx.resize(n);

@@ -146,9 +146,9 @@ PT_DEV f3 xform_normal(const float* minv, f3 n)
 }
 
 // Mesh::RayTriMT (Mesh.cpp:418-445) on the precomputed v0,e1,e2.
-PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float& t, float& u, float& v, int& group)
+PT_DEV bool tri_test(const float4* __restrict__ tp, uint32_t stride, f3 o, f3 d, float& t, float& u, float& v, int& group)
 {
-    float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+    float4 q0 = tp[0], q1 = tp[stride], q2 = tp[2 * stride];
     group = __float_as_int(q2.y);
     f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
     f3 p = cross(d, e2);
@@ -182,23 +182,45 @@ PT_DEV bool alpha_pass(const DScene& sc, const DMesh& me, int tri, int group, fl
     return !(alpha < g.alpha_cutoff);
 }
 
-// Iterative BVH traversal (replaces the stack walk of Mesh.cpp:79-149): near child first, far child
-// pushed on a per-lane stack kept in LDS (column `lane_slot` of a [depth][block] array).
-template <int BLOCK>
-PT_DEV void mesh_traverse(const DScene& sc, const DMesh& me, f3 o, f3 d, float tMinObj, float& closestT,
-                          int& bestTri, float& bu, float& bv, uint32_t* __restrict__ stack, int slot)
+// Where the traversal reads BVH nodes and hot triangles from: the global arrays of the scene, or a copy of
+// them that the workgroup staged into LDS (scenes of a few KB). Indexing is identical in both.
+// node_stride / tri_stride: distance in float4 between the k-th and (k+1)-th float4 of one record; records are
+// node_step / tri_step float4 apart. Global memory keeps records contiguous (stride 1, step 4 or 3: one cache
+// line per record); the LDS copy is column-major (stride = record count, step 1) so that the 16-byte reads of
+// lanes holding different records spread over all banks instead of the 4 bank groups a 64-byte pitch allows.
+struct Geom { const float4* nodes; const float4* tris; uint32_t node_stride, node_step, tri_stride, tri_step; };
+
+// Iterative BVH traversal (replaces the stack walk of Mesh.cpp:79-149), "while-while" form: all lanes of a
+// wave first descend through inner nodes until each holds a leaf (or has run out of work), then all of them
+// test their leaf's triangles, so the two code bodies are never issued for a partial wave inside one loop
+// trip. Near child first (Mesh.cpp:142-145); the far child goes on a per-lane stack kept in LDS (column
+// `slot` of a [depth][BLOCK] array, so a wave's pushes and pops hit 64 different banks). A popped inner node
+// that has fallen behind the closest hit costs one visit (both child tests fail against closestT); storing
+// entry distances to drop such entries on pop was measured slower (8-byte stack traffic, more LDS per block).
+struct TraversalCounts { uint32_t nodes, tris; };
+typedef uint32_t StackEntry;
+
+template <int BLOCK, bool COUNT>
+PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f3 o, f3 d, float tMinObj, float& closestT,
+                          int& bestTri, float& bu, float& bv, StackEntry* __restrict__ stack, int slot, TraversalCounts& cnt)
 {
-    const float4* __restrict__ nodes = sc.nodes + (size_t)me.node_base * 4;
-    const float4* __restrict__ tris = sc.tris + (size_t)me.tri_base * 3;
+    const float4* __restrict__ nodes = geom.nodes + (size_t)me.node_base * geom.node_step;
+    const float4* __restrict__ tris = geom.tris + (size_t)me.tri_base * geom.tri_step;
+    const uint32_t ns = geom.node_stride, nstep = geom.node_step, ts = geom.tri_stride, tstep = geom.tri_step;
     const float BIG = 1e30f;
     f3 inv = mk3(fabsf(d.x) > 1e-30f ? frcp(d.x) : BIG, fabsf(d.y) > 1e-30f ? frcp(d.y) : BIG, fabsf(d.z) > 1e-30f ? frcp(d.z) : BIG);
     f3 oi = o * inv;
+    constexpr int kDone = 0x7fffffff; // never a valid node index
     int sp = 0;
     int cur = me.root;
-    for (;;) {
-        if (cur >= 0) {
-            const float4* n = nodes + (size_t)cur * 4;
-            float4 a = n[0], b = n[1], c = n[2], r = n[3];
+    auto pop = [&]() {
+        if (sp > 0) { --sp; cur = (int)stack[sp * BLOCK + slot]; } else cur = kDone;
+    };
+    while (cur != kDone) {
+        while ((uint32_t)cur < (uint32_t)kDone) { // inner node
+            if (COUNT) ++cnt.nodes;
+            const float4* n = nodes + (size_t)cur * nstep;
+            float4 a = n[0], b = n[ns], c = n[2 * ns], r = n[3 * ns];
             float lx0 = fmaf(a.x, inv.x, -oi.x), lx1 = fmaf(a.w, inv.x, -oi.x);
             float ly0 = fmaf(a.y, inv.y, -oi.y), ly1 = fmaf(b.x, inv.y, -oi.y);
             float lz0 = fmaf(a.z, inv.z, -oi.z), lz1 = fmaf(b.y, inv.z, -oi.z);
@@ -216,31 +238,33 @@ PT_DEV void mesh_traverse(const DScene& sc, const DMesh& me, f3 o, f3 d, float t
                 stack[sp * BLOCK + slot] = (uint32_t)(leftNear ? right : left);
                 ++sp;
                 cur = leftNear ? left : right;
-                continue;
+            } else if (hl || hr) {
+                cur = hl ? left : right;
+            } else {
+                pop();
             }
-            if (hl) { cur = left; continue; }
-            if (hr) { cur = right; continue; }
-        } else {
+        }
+        if (cur < 0) { // leaf
             uint32_t code = ~(uint32_t)cur;
-            uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt; ++i) {
+            uint32_t first = code >> 3, cnt_tris = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt_tris; ++i) {
+                if (COUNT) ++cnt.tris;
                 float t, u, v; int group;
-                if (!tri_test(tris + (size_t)(first + i) * 3, o, d, t, u, v, group)) continue;
+                if (!tri_test(tris + (size_t)(first + i) * tstep, ts, o, d, t, u, v, group)) continue;
                 if (t < tMinObj || t >= closestT) continue; // Mesh.cpp:104
                 if ((me.flags & 1u) && group >= 0 && !alpha_pass(sc, me, (int)(first + i), group, u, v)) continue; // Mesh.cpp:106-125
                 closestT = t; bestTri = (int)(first + i); bu = u; bv = v;
             }
+            pop();
         }
-        if (sp == 0) break;
-        --sp;
-        cur = (int)stack[sp * BLOCK + slot];
     }
 }
 
 // Closest-hit loop of PathTracer::TraceRay (PathTracer.cpp:38-57) over the flat object list.
-template <int BLOCK>
-PT_DEV Best closest_hit(const DScene& sc, const Ray& ray, uint32_t* __restrict__ stack, int slot)
+template <int BLOCK, bool COUNT = false>
+PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, StackEntry* __restrict__ stack, int slot, TraversalCounts* counts = nullptr)
 {
+    TraversalCounts cnt; cnt.nodes = 0; cnt.tris = 0;
     const float kTMin = 1e-4f, kTMax = 1e30f;
     Best best; best.t = kTMax; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
     for (int i = 0; i < sc.num_objects; ++i) {
@@ -263,13 +287,14 @@ PT_DEV Best closest_hit(const DScene& sc, const Ray& ray, uint32_t* __restrict__
             float tMinObj = kTMin * dirLen;
             float closestT = best.t * dirLen;      // Mesh.cpp:72-75
             int tri = -1; float u = 0.f, v = 0.f;
-            mesh_traverse<BLOCK>(sc, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot);
+            mesh_traverse<BLOCK, COUNT>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt);
             if (tri >= 0) {
                 float tW = closestT * invLen;      // Mesh.cpp:249
                 if (tW < best.t) { best.t = tW; best.obj = i; best.tri = tri; best.u = u; best.v = v; }
             }
         }
     }
+    if (COUNT) *counts = cnt;
     return best;
 }
 

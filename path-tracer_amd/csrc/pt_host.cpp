@@ -19,7 +19,7 @@
 namespace ptamd {
 hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t stream);
 hipError_t launch_camera_rays(const DCamera& cam, float* d_out, hipStream_t stream);
-hipError_t launch_closest_hits(const DScene& sc, const float* d_rays, uint32_t n, float* d_rec, hipStream_t stream);
+hipError_t launch_closest_hits(const DScene& sc, const float* d_rays, uint32_t n, float* d_rec, uint32_t* d_counts, hipStream_t stream);
 hipError_t launch_average(const float* accum, const uint32_t* samples, int n, float* avg, hipStream_t stream);
 hipError_t launch_resolve(const float* accum, const uint32_t* samples, int n, int tonemap, int colourspace, uint32_t* rgba, hipStream_t stream);
 int max_stack_depth();
@@ -489,6 +489,9 @@ int ptamd_scene_commit(ptamd_scene* s)
     ds.shade = reinterpret_cast<const float4*>(s->d_shade.ptr);
     ds.groups = s->d_groups.ptr; ds.images = s->d_images.ptr; ds.texels = s->d_texels.ptr;
     std::memcpy(ds.background, s->background, 12);
+    ds.num_nodes = (uint32_t)nodes.size(); ds.num_tris = (uint32_t)tris.size();
+    ds.max_stack = 1;
+    for (const HostObject& ho : s->objects) if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, ho.mesh->bvh.depth);
     s->committed = true;
     return PTAMD_OK;
 }
@@ -684,22 +687,30 @@ int ptamd_camera_rays(const ptamd_camera* cam, int w, int h, float* out)
     PT_HIP(e);
     return PTAMD_OK;
 }
-int ptamd_closest_hits(ptamd_scene* s, const float* rays, uint32_t n, float* rec)
+static int closest_hits_impl(ptamd_scene* s, const float* rays, uint32_t n, float* rec, uint32_t* counts)
 {
     if (!s || !rays || !rec) return fail(PTAMD_ERR_ARG, "null argument");
     if (int rc = need_init()) return rc;
     if (!s->committed) return fail(PTAMD_ERR_STATE, "scene has uncommitted edits: call ptamd_scene_commit first");
     if (n == 0) return PTAMD_OK;
-    float *d_rays = nullptr, *d_rec = nullptr;
+    float *d_rays = nullptr, *d_rec = nullptr; uint32_t* d_cnt = nullptr;
     PT_HIP(hipMalloc(reinterpret_cast<void**>(&d_rays), (size_t)n * 24));
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_rec), (size_t)n * 80);
+    if (e == hipSuccess && counts) e = hipMalloc(reinterpret_cast<void**>(&d_cnt), (size_t)n * 8);
     if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, (size_t)n * 24, hipMemcpyHostToDevice, g_stream);
-    if (e == hipSuccess) e = launch_closest_hits(s->dscene, d_rays, n, d_rec, g_stream);
+    if (e == hipSuccess) e = launch_closest_hits(s->dscene, d_rays, n, d_rec, d_cnt, g_stream);
     if (e == hipSuccess) e = hipMemcpyAsync(rec, d_rec, (size_t)n * 80, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess && counts) e = hipMemcpyAsync(counts, d_cnt, (size_t)n * 8, hipMemcpyDeviceToHost, g_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
-    (void)hipFree(d_rays); (void)hipFree(d_rec);
+    (void)hipFree(d_rays); (void)hipFree(d_rec); if (d_cnt) (void)hipFree(d_cnt);
     PT_HIP(e);
     return PTAMD_OK;
+}
+int ptamd_closest_hits(ptamd_scene* s, const float* rays, uint32_t n, float* rec) { return closest_hits_impl(s, rays, n, rec, nullptr); }
+int ptamd_traversal_counts(ptamd_scene* s, const float* rays, uint32_t n, float* rec, uint32_t* counts)
+{
+    if (!counts) return fail(PTAMD_ERR_ARG, "null argument");
+    return closest_hits_impl(s, rays, n, rec, counts);
 }
 
 } // extern "C"

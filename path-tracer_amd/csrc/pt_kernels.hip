@@ -11,7 +11,27 @@
 namespace ptamd {
 
 constexpr int kBlock = 256;      // 4 waves, each owning one 8x8 tile
-constexpr int kStackDepth = 32;  // per-lane traversal stack entries held in LDS
+constexpr int kStackDepth = 32;  // deepest BVH (inner levels) the kernels can traverse: per-lane stack entries in LDS
+constexpr int kLdsGeomF4 = 1536; // up to 24 KB of BVH nodes + hot triangles of a small scene are staged into LDS
+
+// Copies the scene's nodes and hot triangles into LDS (when they fit) and returns where traversal reads them.
+template <bool LDS_GEOM>
+PT_DEV Geom stage_geometry(const DScene& sc, float4* lds_geom)
+{
+    Geom g;
+    if (LDS_GEOM) {
+        const uint32_t nn = sc.num_nodes, nt = sc.num_tris, n4 = nn * 4u, t4 = nt * 3u;
+        for (uint32_t i = threadIdx.x; i < n4; i += kBlock) lds_geom[(i & 3u) * nn + (i >> 2)] = sc.nodes[i]; // transpose to column-major
+        for (uint32_t i = threadIdx.x; i < t4; i += kBlock) lds_geom[n4 + (i % 3u) * nt + i / 3u] = sc.tris[i];
+        __syncthreads();
+        g.nodes = lds_geom; g.tris = lds_geom + n4;
+        g.node_stride = nn; g.node_step = 1; g.tri_stride = nt; g.tri_step = 1;
+    } else {
+        g.nodes = sc.nodes; g.tris = sc.tris;
+        g.node_stride = 1; g.node_step = 4; g.tri_stride = 1; g.tri_step = 3;
+    }
+    return g;
+}
 
 // Film::AddSample (Film.cpp:34-46) on a register accumulator.
 PT_DEV void add_sample(f3& acc, f3 c)
@@ -21,10 +41,14 @@ PT_DEV void add_sample(f3& acc, f3 c)
     acc = acc + c;
 }
 
-template <int STACK>
+// Dynamic LDS layout: [STACK][kBlock] traversal stack entries, then (LDS_GEOM) the staged nodes and triangles.
+template <int STACK, bool LDS_GEOM>
 __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DRenderParams rp)
 {
-    __shared__ uint32_t stack[STACK * kBlock];
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    StackEntry* stack = reinterpret_cast<StackEntry*>(lds_raw);
+    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + (size_t)STACK * kBlock * sizeof(StackEntry));
+    const Geom geom = stage_geometry<LDS_GEOM>(sc, lds_geom);
     const int slot = threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -54,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DRenderParams
 
     while (s < s_end) {
         ++nrays;
-        Best best = closest_hit<kBlock>(sc, ray, stack, slot);
+        Best best = closest_hit<kBlock>(sc, geom, ray, stack, slot);
         bool done;
         if (best.obj < 0) {
             L = L + T * bg;                       // PathTracer.cpp:59-60
@@ -116,15 +140,19 @@ __global__ void camera_rays_kernel(DCamera cam, float* out)
 
 // Closest-hit probe: 20 floats per ray {hit, t, p, n, frontFace, material(11)}.
 template <int STACK>
-__global__ __launch_bounds__(kBlock) void closest_hits_kernel(DScene sc, const float* rays, uint32_t n, float* rec)
+__global__ __launch_bounds__(kBlock) void closest_hits_kernel(DScene sc, const float* rays, uint32_t n, float* rec, uint32_t* counts)
 {
-    __shared__ uint32_t stack[STACK * kBlock];
+    __shared__ StackEntry stack[STACK * kBlock];
+    Geom geom; geom.nodes = sc.nodes; geom.tris = sc.tris;
+    geom.node_stride = 1; geom.node_step = 4; geom.tri_stride = 1; geom.tri_step = 3;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Ray ray;
     ray.o = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
     ray.d = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-    Best best = closest_hit<kBlock>(sc, ray, stack, (int)threadIdx.x);
+    TraversalCounts tc;
+    Best best = closest_hit<kBlock, true>(sc, geom, ray, stack, (int)threadIdx.x, &tc);
+    if (counts) { counts[2 * (size_t)i] = tc.nodes; counts[2 * (size_t)i + 1] = tc.tris; }
     float* o = rec + (size_t)i * 20;
     for (int k = 0; k < 20; ++k) o[k] = 0.f;
     if (best.obj < 0) return;
@@ -180,7 +208,14 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     int tiles = rp.tiles_x * rp.tiles_y;
     int blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_kernel<kStackDepth>, dim3(blocks), dim3(kBlock), 0, stream, sc, rp);
+    const uint32_t geomF4 = sc.num_nodes * 4u + sc.num_tris * 3u;
+    const bool fits = geomF4 <= (uint32_t)kLdsGeomF4;
+    const size_t geomBytes = fits ? (size_t)geomF4 * 16 : 0;
+    auto lds = [&](int stack) { return (size_t)stack * kBlock * sizeof(StackEntry) + geomBytes; };
+    if (fits && sc.max_stack <= 8) hipLaunchKernelGGL((render_kernel<8, true>), dim3(blocks), dim3(kBlock), lds(8), stream, sc, rp);
+    else if (fits && sc.max_stack <= 16) hipLaunchKernelGGL((render_kernel<16, true>), dim3(blocks), dim3(kBlock), lds(16), stream, sc, rp);
+    else if (sc.max_stack <= 16) hipLaunchKernelGGL((render_kernel<16, false>), dim3(blocks), dim3(kBlock), lds(16), stream, sc, rp);
+    else hipLaunchKernelGGL((render_kernel<kStackDepth, false>), dim3(blocks), dim3(kBlock), lds(kStackDepth), stream, sc, rp);
     return hipGetLastError();
 }
 hipError_t launch_camera_rays(const DCamera& cam, float* d_out, hipStream_t stream)
@@ -189,10 +224,10 @@ hipError_t launch_camera_rays(const DCamera& cam, float* d_out, hipStream_t stre
     hipLaunchKernelGGL(camera_rays_kernel, grid, dim3(64), 0, stream, cam, d_out);
     return hipGetLastError();
 }
-hipError_t launch_closest_hits(const DScene& sc, const float* d_rays, uint32_t n, float* d_rec, hipStream_t stream)
+hipError_t launch_closest_hits(const DScene& sc, const float* d_rays, uint32_t n, float* d_rec, uint32_t* d_counts, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(closest_hits_kernel<kStackDepth>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, d_rays, n, d_rec);
+    hipLaunchKernelGGL(closest_hits_kernel<kStackDepth>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, d_rays, n, d_rec, d_counts);
     return hipGetLastError();
 }
 hipError_t launch_average(const float* accum, const uint32_t* samples, int n, float* avg, hipStream_t stream)

@@ -95,6 +95,8 @@ struct DScene {
     const DImage* images;
     const uint8_t* texels;
     float background[3]; int32_t pad;
+    uint32_t num_nodes, num_tris; // totals over all meshes (what an LDS-staged copy holds)
+    uint32_t pad1, pad2;
 };
 
 // Camera matrices as Camera::CalculateMatrices leaves them (Camera.cpp:22-35), glm column-major.

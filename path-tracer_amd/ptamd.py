@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptamd.so")
+LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(_HERE, "libptamd.so")  # PTAMD_LIB: development builds for A/B timing
 
 
 class PtamdError(RuntimeError):
@@ -74,7 +74,7 @@ EXPORTS = [
     "ptamd_film_create", "ptamd_film_create_external", "ptamd_film_destroy", "ptamd_film_resize",
     "ptamd_film_reset", "ptamd_film_size", "ptamd_film_read", "ptamd_film_average",
     "ptamd_film_resolve_rgba8", "ptamd_film_device_ptrs", "ptamd_render", "ptamd_render_stats",
-    "ptamd_camera_rays", "ptamd_closest_hits",
+    "ptamd_camera_rays", "ptamd_closest_hits", "ptamd_traversal_counts",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def lib():
         L.ptamd_render_stats.argtypes = [C.POINTER(CStats)]
         L.ptamd_camera_rays.argtypes = [C.POINTER(CCamera), C.c_int, C.c_int, vp]
         L.ptamd_closest_hits.argtypes = [vp, vp, C.c_uint32, vp]
+        L.ptamd_traversal_counts.argtypes = [vp, vp, C.c_uint32, vp, vp]
         _lib = L
     return _lib
 
@@ -370,6 +371,14 @@ class PathTracer:
         out = np.zeros((r.shape[0], 20), np.float32)
         check(lib().ptamd_closest_hits(self._h, r.ctypes.data, r.shape[0], out.ctypes.data))
         return out
+
+    def TraversalCounts(self, rays):
+        """(records, counts): counts[:, 0] BVH nodes visited, counts[:, 1] triangle tests per ray on the GPU."""
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        out = np.zeros((r.shape[0], 20), np.float32)
+        cnt = np.zeros((r.shape[0], 2), np.uint32)
+        check(lib().ptamd_traversal_counts(self._h, r.ctypes.data, r.shape[0], out.ctypes.data, cnt.ctypes.data))
+        return out, cnt
 
     def close(self):
         if self._h:
