@@ -531,8 +531,8 @@ PT_DEV bool sample_bsdf(const HitInfo& h, Ray& ray, float& ior, f3& weight, uint
 PT_DEV Ray camera_ray(const DCamera& cam, int px, int py)
 {
     const float* P = cam.inv_proj; const float* V = cam.inv_view;
-    float nx = (((float)px + 0.5f) / (float)cam.width) * 2.f - 1.f;
-    float ny = (((float)py + 0.5f) / (float)cam.height) * 2.f - 1.f;
+    float nx = (((float)px + 0.5f) * frcp((float)cam.width)) * 2.f - 1.f;
+    float ny = (((float)py + 0.5f) * frcp((float)cam.height)) * 2.f - 1.f;
     // invProj * (nx, ny, -+1, 1): (m0*x + m1*y) + (m2*z + m3*w)
     float nr[4], fr[4];
 #pragma unroll
@@ -541,8 +541,9 @@ PT_DEV Ray camera_ray(const DCamera& cam, int px, int py)
         nr[r] = xy + (P[8 + r] * -1.f + P[12 + r]);
         fr[r] = xy + (P[8 + r] * 1.f + P[12 + r]);
     }
-    f3 cn = mk3(nr[0] / nr[3], nr[1] / nr[3], nr[2] / nr[3]);
-    f3 cf = mk3(fr[0] / fr[3], fr[1] / fr[3], fr[2] / fr[3]);
+    float inr = frcp(nr[3]), ifr = frcp(fr[3]);
+    f3 cn = mk3(nr[0] * inr, nr[1] * inr, nr[2] * inr);
+    f3 cf = mk3(fr[0] * ifr, fr[1] * ifr, fr[2] * ifr);
     f3 dc = normalize(cf - cn);
     f3 dw = mk3(V[0] * dc.x + V[4] * dc.y + V[8] * dc.z, V[1] * dc.x + V[5] * dc.y + V[9] * dc.z, V[2] * dc.x + V[6] * dc.y + V[10] * dc.z);
     Ray ray;

@@ -42,12 +42,16 @@ PT_DEV void add_sample(f3& acc, f3 c)
 }
 
 // Dynamic LDS layout: [STACK][kBlock] traversal stack entries, then (LDS_GEOM) the staged nodes and triangles.
+// Occupancy: the bounce loop is latency bound (dependent VALU chains, LDS and L1 round trips), and its
+// throughput scales almost linearly with resident waves up to 5 per SIMD; asking for 5 holds the register
+// allocator to 96 VGPRs, which it meets without spilling. 6 (80 VGPRs) and 8 (64) spill into the loop and lose.
 template <int STACK, bool LDS_GEOM>
-__global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DRenderParams rp)
+__global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderParams rp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     StackEntry* stack = reinterpret_cast<StackEntry*>(lds_raw);
-    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + (size_t)STACK * kBlock * sizeof(StackEntry));
+    float* lds_acc = reinterpret_cast<float*>(lds_raw + (size_t)STACK * kBlock * sizeof(StackEntry)); // [3][kBlock] film sums
+    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + (size_t)(STACK * sizeof(StackEntry) + 12) * kBlock);
     const Geom geom = stage_geometry<LDS_GEOM>(sc, lds_geom);
     const int slot = threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -63,12 +67,16 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DRenderParams
     const uint32_t s_end = (inside && rp.depth > 0) ? rp.spp_begin + rp.spp_count : rp.spp_begin;
     const uint32_t seed_hash = pcg_hash(rp.seed);
 
-    Ray primary = camera_ray(rp.cam, px, py);
-    f3 acc = mk3(0.f, 0.f, 0.f);
-    if (inside) acc = mk3(rp.accum[3 * (size_t)pixel], rp.accum[3 * (size_t)pixel + 1], rp.accum[3 * (size_t)pixel + 2]);
+    // The running film sum of this lane's pixel lives in LDS, not in registers: it is touched once per sample,
+    // and three more live VGPRs through the whole bounce loop would cost occupancy.
+    {
+        f3 a0 = mk3(0.f, 0.f, 0.f);
+        if (inside) a0 = mk3(rp.accum[3 * (size_t)pixel], rp.accum[3 * (size_t)pixel + 1], rp.accum[3 * (size_t)pixel + 2]);
+        lds_acc[slot] = a0.x; lds_acc[kBlock + slot] = a0.y; lds_acc[2 * kBlock + slot] = a0.z;
+    }
 
-    // path state
-    Ray ray = primary;
+    // path state; the primary ray is recomputed for every sample (no jitter: Camera.cpp:47-48) instead of held
+    Ray ray = camera_ray(rp.cam, px, py);
     float ior = 1.0f;
     f3 T = mk3(1.f, 1.f, 1.f), L = mk3(0.f, 0.f, 0.f);
     int bounce = 0;
@@ -103,9 +111,11 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DRenderParams
             }
         }
         if (done) {
+            f3 acc = mk3(lds_acc[slot], lds_acc[kBlock + slot], lds_acc[2 * kBlock + slot]);
             add_sample(acc, L);
+            lds_acc[slot] = acc.x; lds_acc[kBlock + slot] = acc.y; lds_acc[2 * kBlock + slot] = acc.z;
             ++s;
-            ray = primary; ior = 1.0f;
+            ray = camera_ray(rp.cam, px, py); ior = 1.0f;
             T = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f);
             bounce = 0;
             key = path_key(seed_hash, pixel, s);
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DRenderParams
     }
 
     if (inside) {
-        rp.accum[3 * (size_t)pixel] = acc.x; rp.accum[3 * (size_t)pixel + 1] = acc.y; rp.accum[3 * (size_t)pixel + 2] = acc.z;
+        rp.accum[3 * (size_t)pixel] = lds_acc[slot]; rp.accum[3 * (size_t)pixel + 1] = lds_acc[kBlock + slot]; rp.accum[3 * (size_t)pixel + 2] = lds_acc[2 * kBlock + slot];
         rp.samples[pixel] += rp.spp_count;
     }
     if (rp.counters) {
@@ -211,7 +221,7 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const uint32_t geomF4 = sc.num_nodes * 4u + sc.num_tris * 3u;
     const bool fits = geomF4 <= (uint32_t)kLdsGeomF4;
     const size_t geomBytes = fits ? (size_t)geomF4 * 16 : 0;
-    auto lds = [&](int stack) { return (size_t)stack * kBlock * sizeof(StackEntry) + geomBytes; };
+    auto lds = [&](int stack) { return ((size_t)stack * sizeof(StackEntry) + 12) * kBlock + geomBytes; };
     if (fits && sc.max_stack <= 8) hipLaunchKernelGGL((render_kernel<8, true>), dim3(blocks), dim3(kBlock), lds(8), stream, sc, rp);
     else if (fits && sc.max_stack <= 16) hipLaunchKernelGGL((render_kernel<16, true>), dim3(blocks), dim3(kBlock), lds(16), stream, sc, rp);
     else if (sc.max_stack <= 16) hipLaunchKernelGGL((render_kernel<16, false>), dim3(blocks), dim3(kBlock), lds(16), stream, sc, rp);
