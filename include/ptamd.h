@@ -85,13 +85,15 @@ typedef struct ptamd_rect { int32_t x0, y0, x1, y1; } ptamd_rect; /* [x0,x1) x [
 typedef struct ptamd_stats {
     uint64_t samples; /* paths started (top-level TraceRay calls) */
     uint64_t rays;    /* rays cast, primary + bounces */
+    uint64_t nodes;   /* BVH inner-node visits (each tests both child boxes) */
+    uint64_t tris;    /* ray-triangle tests */
 } ptamd_stats;
 
 typedef struct ptamd_scene ptamd_scene;
 typedef struct ptamd_film ptamd_film;
 typedef struct ptamd_model ptamd_model;
 
-#define PTAMD_FLAG_COUNT 1u  /* count samples and rays (one wave-aggregated atomic per wave at kernel end) */
+#define PTAMD_FLAG_COUNT 1u  /* fill ptamd_stats (a counting build of the kernel: slower, not for timing) */
 
 /* ---- context ------------------------------------------------------------------------------ */
 /* Selects the HIP device for this process and creates the library's stream.  No reference

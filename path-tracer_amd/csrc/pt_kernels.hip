@@ -45,7 +45,8 @@ PT_DEV void add_sample(f3& acc, f3 c)
 // Occupancy: the bounce loop is latency bound (dependent VALU chains, LDS and L1 round trips), and its
 // throughput scales almost linearly with resident waves up to 5 per SIMD; asking for 5 holds the register
 // allocator to 96 VGPRs, which it meets without spilling. 6 (80 VGPRs) and 8 (64) spill into the loop and lose.
-template <int STACK, bool LDS_GEOM>
+// COUNT: also tally rays, BVH node visits and triangle tests (PTAMD_FLAG_COUNT); kept out of the timed build.
+template <int STACK, bool LDS_GEOM, bool COUNT>
 __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderParams rp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -82,11 +83,18 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderPar
     int bounce = 0;
     uint32_t key = path_key(seed_hash, pixel, s);
     uint32_t nrays = 0;
+    TraversalCounts tc_total; tc_total.nodes = 0; tc_total.tris = 0;
     const f3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
 
     while (s < s_end) {
-        ++nrays;
-        Best best = closest_hit<kBlock>(sc, geom, ray, stack, slot);
+        Best best;
+        if (COUNT) {
+            TraversalCounts tc;
+            best = closest_hit<kBlock, true>(sc, geom, ray, stack, slot, &tc);
+            ++nrays; tc_total.nodes += tc.nodes; tc_total.tris += tc.tris;
+        } else {
+            best = closest_hit<kBlock, false>(sc, geom, ray, stack, slot);
+        }
         bool done;
         if (best.obj < 0) {
             L = L + T * bg;                       // PathTracer.cpp:59-60
@@ -126,15 +134,15 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderPar
         rp.accum[3 * (size_t)pixel] = lds_acc[slot]; rp.accum[3 * (size_t)pixel + 1] = lds_acc[kBlock + slot]; rp.accum[3 * (size_t)pixel + 2] = lds_acc[2 * kBlock + slot];
         rp.samples[pixel] += rp.spp_count;
     }
-    if (rp.counters) {
-        // wave-level reduction, then one atomic per wave
-        unsigned long long r = nrays, n = inside ? rp.spp_count : 0u;
+    if (COUNT && rp.counters) {
+        // wave-level reduction, then one atomic per wave and counter
+        unsigned long long c[4] = { inside ? rp.spp_count : 0u, nrays, tc_total.nodes, tc_total.tris };
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            r += __shfl_xor(r, off, 64);
-            n += __shfl_xor(n, off, 64);
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_xor(c[k], off, 64);
+            if (lane == 0) atomicAdd(&rp.counters[k], c[k]);
         }
-        if (lane == 0) { atomicAdd(&rp.counters[0], n); atomicAdd(&rp.counters[1], r); }
     }
 }
 
@@ -222,10 +230,17 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const bool fits = geomF4 <= (uint32_t)kLdsGeomF4;
     const size_t geomBytes = fits ? (size_t)geomF4 * 16 : 0;
     auto lds = [&](int stack) { return ((size_t)stack * sizeof(StackEntry) + 12) * kBlock + geomBytes; };
-    if (fits && sc.max_stack <= 8) hipLaunchKernelGGL((render_kernel<8, true>), dim3(blocks), dim3(kBlock), lds(8), stream, sc, rp);
-    else if (fits && sc.max_stack <= 16) hipLaunchKernelGGL((render_kernel<16, true>), dim3(blocks), dim3(kBlock), lds(16), stream, sc, rp);
-    else if (sc.max_stack <= 16) hipLaunchKernelGGL((render_kernel<16, false>), dim3(blocks), dim3(kBlock), lds(16), stream, sc, rp);
-    else hipLaunchKernelGGL((render_kernel<kStackDepth, false>), dim3(blocks), dim3(kBlock), lds(kStackDepth), stream, sc, rp);
+    const bool count = rp.counters != nullptr;
+#define PT_LAUNCH(STACK, LDSG)                                                                                        \
+    do {                                                                                                              \
+        if (count) hipLaunchKernelGGL((render_kernel<STACK, LDSG, true>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp); \
+        else hipLaunchKernelGGL((render_kernel<STACK, LDSG, false>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);     \
+    } while (0)
+    if (fits && sc.max_stack <= 8) PT_LAUNCH(8, true);
+    else if (fits && sc.max_stack <= 16) PT_LAUNCH(16, true);
+    else if (sc.max_stack <= 16) PT_LAUNCH(16, false);
+    else PT_LAUNCH(kStackDepth, false);
+#undef PT_LAUNCH
     return hipGetLastError();
 }
 hipError_t launch_camera_rays(const DCamera& cam, float* d_out, hipStream_t stream)

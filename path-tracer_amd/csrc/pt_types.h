@@ -110,7 +110,7 @@ struct DRenderParams {
     DCamera cam;
     float* accum;          // w*h*3
     uint32_t* samples;     // w*h
-    unsigned long long* counters; // [0] samples, [1] rays, or null
+    unsigned long long* counters; // [0] samples, [1] rays, [2] BVH node visits, [3] triangle tests, or null
     int32_t x0, y0, x1, y1;
     uint32_t spp_begin, spp_count;
     int32_t depth, albedo_only;

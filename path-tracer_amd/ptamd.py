@@ -58,7 +58,7 @@ class CRect(C.Structure):
 
 
 class CStats(C.Structure):
-    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64)]
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64)]
 
 
 FLAG_COUNT = 1
@@ -511,7 +511,7 @@ def RayTraceParallel(winSize, camera, pathTracer, film, depth, albedoOnly, frame
 def RenderStats():
     s = CStats()
     check(lib().ptamd_render_stats(C.byref(s)))
-    return {"samples": int(s.samples), "rays": int(s.rays)}
+    return {"samples": int(s.samples), "rays": int(s.rays), "nodes": int(s.nodes), "tris": int(s.tris)}
 
 
 def build_scene(scene, mesh_data=None):

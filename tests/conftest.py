@@ -27,6 +27,8 @@ def golden_scenes():
         "mesh_cornell": (presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 54), 8),
         "blob_mixed": (presets.mixed("tests/golden/blob.glb", 96, 96, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0),
                                      mesh_scale=(1.1, 0.9, 1.0)), 8),
+        "textured": (presets.mixed("tests/golden/textured.glb", 96, 96, mesh_pos=(2.7, 1.6, 2.6), mesh_rot=(0.0, 25.0, 0.0),
+                                   mesh_scale=(1.4, 1.4, 1.4)), 6),
     }
 
 

@@ -21,6 +21,47 @@ def lum(a):
     return (a * np.array([0.2126, 0.7152, 0.0722], np.float32)).sum(-1)
 
 
+def write_textured_glb(path):
+    """A .glb that exercises every texture path of the reference (Mesh.cpp:15-37,106-125,170-227,447-486): base
+    colour + alpha MASK cutout, metallic-roughness, emissive, normal map, transmission texture."""
+    rng = np.random.default_rng(11)
+    n = 16
+    yy, xx = np.mgrid[0:n, 0:n]
+    base = np.zeros((n, n, 4), np.uint8)
+    base[..., 0] = 60 + 12 * xx
+    base[..., 1] = 40 + 13 * yy
+    base[..., 2] = rng.integers(30, 255, (n, n))
+    base[..., 3] = np.where(((xx // 2 + yy // 2) % 3) == 0, 40, 255)      # holes for the MASK cutout
+    mr = np.zeros((n, n, 3), np.uint8)
+    mr[..., 1] = rng.integers(20, 255, (n, n))                             # G = roughness
+    mr[..., 2] = np.where((xx + yy) % 4 < 2, 255, 0)                       # B = metallic
+    em = np.zeros((n, n, 3), np.uint8)
+    em[(xx % 5 == 0) & (yy % 5 == 0)] = (255, 180, 90)
+    nm = np.zeros((n, n, 3), np.uint8)
+    nm[..., 0] = 128 + (40 * np.sin(xx * 0.9)).astype(int)
+    nm[..., 1] = 128 + (40 * np.cos(yy * 0.7)).astype(int)
+    nm[..., 2] = 230
+    tr = np.zeros((n, n, 1), np.uint8)
+    tr[..., 0] = np.where(xx < n // 2, 255, 64)
+    images = [base, mr, em, nm, tr]
+    p0 = gltf_io.bumpy_sphere_primitive(24, 32, radius=0.8, bump=0.05, freq=3, material_index=0)
+    p0["uvs"] = p0["uvs"] * np.array([3.0, 2.0], np.float32) - np.float32(0.25)   # wraps and negative uvs
+    p1 = gltf_io.box_primitive((1.2, -0.3, 0.2), (10.0, 20.0, 0.0), (0.7, 0.7, 0.7), 1)
+    p2 = gltf_io.box_primitive((-1.1, 0.5, 0.3), (0.0, 45.0, 30.0), (0.5, 0.9, 0.5), 2)
+    mats = [
+        {"name": "masked_pbr", "alphaMode": "MASK", "alphaCutoff": 0.5, "emissiveFactor": [1.5, 1.5, 1.5],
+         "pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.8, 1.0, 0.9], "baseColorTexture": {"index": 0},
+                                  "metallicFactor": 0.8, "roughnessFactor": 0.9, "metallicRoughnessTexture": {"index": 1}},
+         "emissiveTexture": {"index": 2}, "normalTexture": {"index": 3, "scale": 1.5}},
+        {"name": "glassy", "pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 1], "metallicFactor": 0.0, "roughnessFactor": 0.1},
+         "extensions": {"KHR_materials_transmission": {"transmissionFactor": 0.9, "transmissionTexture": {"index": 4}},
+                        "KHR_materials_ior": {"ior": 1.4}}},
+        {"name": "bumpy_plain", "pbrMetallicRoughness": {"baseColorFactor": [0.3, 0.7, 0.4, 1], "metallicFactor": 0.0},
+         "normalTexture": {"index": 3}},
+    ]
+    gltf_io.write_glb(path, [p0, p1, p2], mats, images)
+
+
 def golden_scenes():
     """name -> (scene dict, depth for the stochastic render)."""
     cm = os.path.join(HERE, "cornell_mesh.glb")
@@ -33,6 +74,8 @@ def golden_scenes():
     mats = [gltf_io.gltf_material("copper", presets.material(albedo=(0.9, 0.5, 0.3), roughness=0.3, metallic=1.0)),
             gltf_io.gltf_material("glass", presets.material(albedo=(1, 1, 1), roughness=0.0, ior=1.45, transmission=1.0))]
     gltf_io.write_glb(blob, [p0, p1], mats)
+    write_textured_glb(os.path.join(HERE, "textured.glb"))
+    tex_scene = presets.mixed("tests/golden/textured.glb", 96, 96, mesh_pos=(2.7, 1.6, 2.6), mesh_rot=(0.0, 25.0, 0.0), mesh_scale=(1.4, 1.4, 1.4))
     blob_scene = presets.mixed("tests/golden/blob.glb", 96, 96, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
     return {
         "sphere_cornell": (presets.sphere_cornell(96, 96), 5),
@@ -40,6 +83,7 @@ def golden_scenes():
         "box_cornell": (presets.box_cornell(96, 64), 6),
         "mesh_cornell": (presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 54), 8),
         "blob_mixed": (blob_scene, 8),
+        "textured": (tex_scene, 6),
     }
 
 

@@ -71,7 +71,7 @@ def test_no_cpu_fallback_without_device():
     L.ptamd_scene_destroy(s)
 
 
-@pytest.mark.parametrize("fname", ["cornell_mesh.glb", "blob.glb"])
+@pytest.mark.parametrize("fname", ["cornell_mesh.glb", "blob.glb", "textured.glb"])
 def test_gltf_ingest_matches_test_side_loader(fname):
     """ModelLoader::LoadGLTF replacement (C++ in libptamd) vs the independent numpy reader that feeds the oracle
     (the oracle + numpy reader pair is pinned to the reference bit for bit in test_oracle_golden.py)."""
@@ -90,6 +90,9 @@ def test_gltf_ingest_matches_test_side_loader(fname):
                 assert va == np.float32(vb), k
             else:
                 assert va == vb, k
+    assert len(a["images"]) == len(b["images"])
+    for ia, ib in zip(a["images"], b["images"]):
+        assert np.array_equal(ia, ib)
 
 
 def test_gltf_ingest_textures_indices_and_material_quirks(tmp_path):
