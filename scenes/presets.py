@@ -144,6 +144,9 @@ def write_scene_txt(scene, path):
     lines = ["film %d %d" % tuple(scene["film"])]
     c = scene["camera"]
     lines.append("camera %s %s %s %s" % (fl(c["pos"]), fl(c["rot"]), fl([c["fov"]]), fl([c["near"], c["far"]])))
+    bg = tuple(scene.get("background", (0.2, 0.2, 0.2)))
+    if bg != (0.2, 0.2, 0.2):  # the reference's background is a private constant (PathTracer.h:21): its driver rejects this record
+        lines.append("background %s" % fl(bg))
     for o in scene["objects"]:
         if o["type"] == "sphere":
             lines.append("sphere %s %s %s" % (fl(o["pos"]), fl([o["radius"]]), fl(o["mat"])))

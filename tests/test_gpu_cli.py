@@ -1,0 +1,48 @@
+"""GPU test of the headless C++ path: ptamd_cli (host classes of host/ptamd.hpp over the C ABI) renders the
+same film as the Python mirror, and its PNG / PFM / raw outputs hold what Film::ResolveToRGBA8 / AverageAt /
+Accum return (PNG rows flipped as Window::SaveImagePNG does, Window.cpp:173-184)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from scenes import gltf_io, presets
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "path-tracer_amd", "ptamd_cli")
+
+
+def test_cli_matches_python_mirror(gpu, tmp_path):
+    assert os.path.exists(CLI), "ptamd_cli is not built (make -C path-tracer_amd)"
+    scene = presets.mixed("tests/golden/textured.glb", 72, 56, mesh_pos=(2.7, 1.6, 2.6), mesh_rot=(0.0, 25.0, 0.0), mesh_scale=(1.4, 1.4, 1.4))
+    sp = str(tmp_path / "scene.txt")
+    presets.write_scene_txt(scene, sp)
+    w, h = scene["film"]
+    pt, cam = gpu.build_scene(scene)
+    film = gpu.Film(w, h)
+    gpu.Render(cam, pt, film, 5, 4, seed=77)
+    accum, rgba, avg = film.Accum(), film.ResolveToRGBA8(), film.Average()
+    for extra in ([], ["--frames"]):
+        out = subprocess.run([CLI, sp, "--out", str(tmp_path / "img.png"), "--pfm", str(tmp_path / "img.pfm"), "--raw", str(tmp_path / "raw"),
+                              "--spp", "5", "--depth", "4", "--seed", "77"] + extra, check=True, capture_output=True, text=True, cwd=ROOT)
+        info = json.loads(out.stdout.strip().splitlines()[-1])
+        assert info["width"] == w and info["height"] == h and info["objects"] == len(scene["objects"])
+        a = np.fromfile(str(tmp_path / "raw.accum.f32"), np.float32).reshape(h, w, 3)
+        s = np.fromfile(str(tmp_path / "raw.samples.u32"), np.uint32).reshape(h, w)
+        assert np.array_equal(a.view(np.uint32), accum.view(np.uint32)) and np.all(s == 5)
+        png = gltf_io.png_decode(open(tmp_path / "img.png", "rb").read())
+        assert png.shape == (h, w, 4) and np.array_equal(png[::-1], rgba)
+        raw = open(tmp_path / "img.pfm", "rb").read()
+        header = ("PF\n%d %d\n-1.0\n" % (w, h)).encode()
+        assert raw.startswith(header)
+        assert np.array_equal(np.frombuffer(raw[len(header):], np.float32).reshape(h, w, 3), avg)
+
+
+def test_cli_reports_loader_errors(gpu, tmp_path):
+    sp = tmp_path / "bad.txt"
+    sp.write_text("film 8 8\ncamera 0 0 0 0 0 0 45\nmesh /nonexistent/model.glb 0 0 0 0 0 0 1 1 1\n")
+    out = subprocess.run([CLI, str(sp), "--out", str(tmp_path / "x.png")], capture_output=True, text=True)
+    assert out.returncode == 1 and "Failed to load GLTF model" in out.stderr
