@@ -84,6 +84,8 @@ def golden_scenes():
         "mesh_cornell": (presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 54), 8),
         "blob_mixed": (blob_scene, 8),
         "textured": (tex_scene, 6),
+        # 1920/128 = 15 is odd, so pixel (x, y) here has the same centre ray as pixel (15x+7, 15y+7) of the 1080p frame
+        "mesh_cornell_128x72": (presets.mesh_cornell("tests/golden/cornell_mesh.glb", 128, 72), 8),
     }
 
 

@@ -1,0 +1,127 @@
+"""GPU parity cases at the sizes of BASELINE.json's other configurations, checked through properties that do
+not need a full CPU render: a ~1 M-triangle mesh (config 3: BVH in global memory, deep tree), the 4K film of
+config 4 with tile sharding, the 32-bounce glass/mirror scene of config 5, and the full 1080p mesh Cornell of
+config 2."""
+import numpy as np
+import pytest
+
+from conftest import lum
+from oracle import pyoracle as po
+from scenes import gltf_io, presets
+
+pytestmark = pytest.mark.gpu
+
+
+def soup(prim, group=0):
+    idx = prim["indices"].reshape(-1, 3)
+    return {"positions": np.ascontiguousarray(prim["positions"][idx].reshape(-1, 9)),
+            "normals": np.ascontiguousarray(prim["normals"][idx].reshape(-1, 9)),
+            "uvs": np.ascontiguousarray(prim["uvs"][idx].reshape(-1, 6)),
+            "group": np.full(len(idx), group, np.int32),
+            "groups": [dict(gltf_io.default_pbr(), base_color_factor=[0.7, 0.6, 0.5, 1.0], metallic_factor=0.0, roughness_factor=0.6, name="m")],
+            "images": []}
+
+
+@pytest.fixture(scope="module")
+def million_tri_scene():
+    prim = gltf_io.bumpy_sphere_primitive(500, 1000, radius=1.0, bump=0.06, freq=9)
+    data = soup(prim)
+    assert data["positions"].shape[0] > 990_000
+    objs = presets.cornell_room_boxes()
+    objs.append({"type": "mesh", "data": data, "pos": (2.775, 2.2, 2.2), "rot": (20.0, 30.0, 0.0), "scale": (2.3, 2.0, 2.1)})
+    return {"film": (160, 120), "camera": presets.default_camera(), "background": (0.2, 0.2, 0.2), "objects": objs}
+
+
+def test_million_triangle_mesh_hits_and_samples(gpu, million_tri_scene):
+    """Config 3 geometry scale: closest hits against the oracle's median-split BVH (a different tree over the
+    same triangles), then same-seed radiance."""
+    scene = million_tri_scene
+    pt, cam = gpu.build_scene(scene)
+    S = po.Scene(scene)
+    rays = S.rays().reshape(-1, 6)
+    ref = S.closest_hits(rays)
+    got, cnt = pt.TraversalCounts(rays)
+    on_mesh = (ref[:, 0] == 1) & (ref[:, 12] == np.float32(0.6))  # the mesh's roughness factor
+    assert on_mesh.mean() > 0.1
+    assert (got[:, 0] == ref[:, 0]).mean() >= 0.999
+    same = (got[:, 0] == 1) & (ref[:, 0] == 1) & (np.abs(got[:, 1] - ref[:, 1]) <= 2e-5 * np.abs(ref[:, 1]) + 1e-6)
+    assert same.sum() >= 0.997 * (ref[:, 0] == 1).sum()  # silhouettes of ~0.01-unit triangles may pick a neighbour
+    sel = same & on_mesh
+    assert np.abs(got[sel, 2:5] - ref[sel, 2:5]).max() <= 5e-4
+    assert (np.abs(got[sel, 5:8] - ref[sel, 5:8]).max(axis=1) <= 1e-3).mean() >= 0.995
+    assert np.array_equal(got[sel, 8], ref[sel, 8])
+    assert cnt[on_mesh, 0].mean() < 120 and cnt[:, 0].max() < 1000  # the SAH tree is walked, not brute-forced
+    w, h = scene["film"]
+    film = gpu.Film(w, h)
+    gpu.Render(cam, pt, film, 1, 8, seed=3)
+    a = film.Accum()
+    oa, _ = S.render(1, 8, seed=3)
+    close = np.abs(a - oa).max(axis=-1) <= 1e-3 + 1e-3 * np.abs(oa).max(axis=-1)
+    assert close.mean() >= 0.95, close.mean()
+
+
+def test_config5_depth32_same_seed(gpu):
+    """Glass / mirror / rough metal, 32 bounces, no Russian roulette (the reference has none)."""
+    scene = presets.glass_mirror(96, 96)
+    pt, cam = gpu.build_scene(scene)
+    film = gpu.Film(96, 96)
+    gpu.Render(cam, pt, film, 2, 32, seed=9, count=True)
+    st = gpu.RenderStats()
+    assert st["rays"] / st["samples"] > 8  # long specular chains really happen
+    a = film.Accum()
+    oa, _ = po.Scene(scene).render(2, 32, seed=9)
+    close = np.abs(a - oa).max(axis=-1) <= 2e-3 + 2e-3 * np.abs(oa).max(axis=-1)
+    assert close.mean() >= 0.93, close.mean()  # refraction chains amplify rounding: a larger share of paths decorrelate
+    assert abs(lum(a).mean() - lum(oa).mean()) <= 0.03 * lum(oa).mean()
+
+
+def test_config4_4k_film_tile_sharding(gpu):
+    """3840x2160 film, interleaved 32x32 tiles of 8 'ranks' rendered into one film equal the single launch bit
+    for bit; counts are exact."""
+    import shard
+    w, h = 3840, 2160
+    scene = presets.mixed("tests/golden/blob.glb", w, h, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
+    pt, cam = gpu.build_scene(scene)
+    full = gpu.Film(w, h)
+    gpu.Render(cam, pt, full, 2, 3, seed=5)
+    fa = full.Accum()
+    tiled = gpu.Film(w, h)
+    total = 0
+    for rank in range(8):
+        rects = shard.tile_rects(rank, 8, w, h, tile=240)  # coarse tiles keep the launch count of this test low
+        for r in rects:
+            gpu.Render(cam, pt, tiled, 2, 3, seed=5, rect=r)
+            total += (r[2] - r[0]) * (r[3] - r[1])
+    assert total == w * h
+    assert np.array_equal(tiled.Accum().view(np.uint32), fa.view(np.uint32))
+    assert np.array_equal(tiled.Samples(), np.full((h, w), 2, np.uint32))
+
+
+def test_config2_full_size_properties(gpu, golden):
+    """1920x1080 mesh Cornell at 256 spp: exact sample counts, sample-range additivity, and agreement with the
+    reference on the pixels whose centre rays coincide with the reference's 128x72 golden render of the same view
+    (1920 / 128 = 15 is odd: golden pixel (x, y) and frame pixel (15x+7, 15y+7) share their primary ray)."""
+    w, h = 1920, 1080
+    scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", w, h)
+    pt, cam = gpu.build_scene(scene)
+    g = golden("mesh_cornell_128x72")
+    spp = int(g["spp"])
+    film = gpu.Film(w, h)
+    gpu.Render(cam, pt, film, spp, 8, count=True)
+    st = gpu.RenderStats()
+    assert st["samples"] == w * h * spp and 5.5 < st["rays"] / st["samples"] < 7.5
+    assert np.array_equal(film.Samples(), np.full((h, w), spp, np.uint32))
+    A = film.Average()
+    rays = cam.GetRays()[7::15, 7::15]
+    assert np.abs(rays - g["rays"]).max() <= 2e-6
+    sub = A[7::15, 7::15]
+    ra, rb = g["avg_a"].astype(np.float32), g["avg_b"].astype(np.float32)
+    self_rmse = float(g["self_rmse"])
+    rm = lambda x, y: float(np.sqrt(((x - y) ** 2).mean()))
+    assert rm(sub, ra) <= 1.25 * self_rmse and rm(sub, rb) <= 1.25 * self_rmse
+    ref_lum = 0.5 * (float(g["mean_lum_a"]) + float(g["mean_lum_b"]))
+    assert abs(lum(sub).mean() - ref_lum) <= 0.02 * ref_lum
+    f2 = gpu.Film(w, h)
+    gpu.Render(cam, pt, f2, 100, 8, spp_begin=0)
+    gpu.Render(cam, pt, f2, spp - 100, 8, spp_begin=100)
+    assert np.array_equal(f2.Accum()[::7].view(np.uint32), film.Accum()[::7].view(np.uint32))
