@@ -94,6 +94,12 @@ typedef struct ptamd_film ptamd_film;
 typedef struct ptamd_model ptamd_model;
 
 #define PTAMD_FLAG_COUNT 1u  /* fill ptamd_stats (a counting build of the kernel: slower, not for timing) */
+/* No reference counterpart (its bounce loop always runs to maxDepth, PathTracer.cpp:35-36): from the third
+ * bounce on a path continues with probability q = clamp(max(throughput), 0.05, 1) and is divided by q.
+ * Leaves the expected radiance unchanged; what reaches the film can still differ a little because
+ * Film::AddSample clips each sample's luminance at 12 (Film.cpp:38-43) and rescaled samples reach that
+ * clamp more often. Off by default so that default renders follow the reference. */
+#define PTAMD_FLAG_RUSSIAN_ROULETTE 2u
 
 /* ---- context ------------------------------------------------------------------------------ */
 /* Selects the HIP device for this process and creates the library's stream.  No reference
@@ -136,6 +142,11 @@ int ptamd_scene_set_material(ptamd_scene* s, int object, const ptamd_material* m
 int ptamd_scene_set_mesh_group(ptamd_scene* s, int object, uint32_t group, const ptamd_pbr* pbr);
 /* PathTracer::mBackgroundColour (PathTracer.h:21); default (0.2, 0.2, 0.2). */
 int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3]);
+/* No reference counterpart (a miss returns the constant above, PathTracer.cpp:59-60): a cubemap whose
+ * texel replaces that constant. faces: +x, -x, +y, -y, +z, -z, each face_size x face_size RGBA8, row 0 at
+ * the top, OpenGL cubemap orientation; radiance = texel / 255 * intensity (nearest texel, no sRGB decode).
+ * faces == NULL or face_size <= 0 removes it. Takes effect at once; no commit needed. */
+int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const faces[6], float intensity);
 /* Flattens the object list into SoA device buffers, builds and linearises the per-mesh BVHs
  * (replaces Mesh::BuildBVH, Mesh.cpp:289-397) and uploads. Re-callable after edits; only meshes
  * whose triangles changed are rebuilt. */

@@ -196,7 +196,7 @@ float po_rand01(uint32_t key, uint32_t bounce, uint32_t draw)
     uint32_t r = po_pcg_hash(key + bounce * 8u + draw);
     return (float)(r >> 8) * 5.9604644775390625e-8f;
 }
-typedef struct { uint32_t key, bounce, draw; } rng_t;
+typedef struct { uint32_t key, bounce, draw; uint32_t flags; v3 thr; } rng_t; /* flags/thr: extension state (Russian roulette) */
 static inline float Rand01(rng_t* g) { return po_rand01(g->key, g->bounce, g->draw++); }
 
 /* ------------------------------------------------------------------ scene types */
@@ -232,6 +232,7 @@ typedef struct {
 struct po_scene {
     object_t* objs; int nobjs, cap;
     v3 background; /* PathTracer.h:21 */
+    int sky_size; uint8_t* sky; float sky_intensity; /* extension: cubemap, 6 * size * size * 4 bytes */
 };
 
 typedef struct { po_counters c; } tls_counters;
@@ -255,7 +256,31 @@ void po_scene_destroy(po_scene* s)
 {
     if (!s) return;
     for (int i = 0; i < s->nobjs; ++i) mesh_free(s->objs[i].mesh);
-    free(s->objs); free(s);
+    free(s->objs); free(s->sky); free(s);
+}
+void po_scene_set_skybox(po_scene* s, int size, const uint8_t* const faces[6], float intensity)
+{
+    free(s->sky); s->sky = NULL; s->sky_size = 0;
+    if (!faces || size <= 0) return;
+    size_t fb = (size_t)size * size * 4;
+    s->sky = (uint8_t*)malloc(6 * fb);
+    for (int f = 0; f < 6; ++f) memcpy(s->sky + f * fb, faces[f], fb);
+    s->sky_size = size; s->sky_intensity = intensity;
+}
+/* Extension (no reference counterpart): miss radiance from a cubemap, OpenGL face selection and orientation. */
+static v3 sky_lookup(const po_scene* s, v3 d)
+{
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int face; float sc, tc, ma;
+    if (ax >= ay && ax >= az) { ma = ax; if (d.x > 0) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
+    else if (ay >= az) { ma = ay; if (d.y > 0) { face = 2; sc = d.x; tc = d.z; } else { face = 3; sc = d.x; tc = -d.z; } }
+    else { ma = az; if (d.z > 0) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+    float u = (sc / ma + 1.0f) * 0.5f, v = (tc / ma + 1.0f) * 0.5f;
+    int n = s->sky_size;
+    int x = (int)(u * (float)n), y = (int)(v * (float)n);
+    x = x < 0 ? 0 : (x > n - 1 ? n - 1 : x); y = y < 0 ? 0 : (y > n - 1 ? n - 1 : y);
+    const uint8_t* t = s->sky + (((size_t)face * n + y) * n + x) * 4;
+    return scl3(V3((float)t[0] / 255.0f, (float)t[1] / 255.0f, (float)t[2] / 255.0f), s->sky_intensity);
 }
 void po_scene_set_background(po_scene* s, const float rgb[3]) { s->background = V3(rgb[0], rgb[1], rgb[2]); }
 static object_t* push_obj(po_scene* s)
@@ -779,6 +804,21 @@ static v3 sample_half(float roughness, float alpha, rng_t* g)
     float sinT = sqrtf(fmaxr(0.0f, 1.0f - cosT * cosT));
     return norm3(V3(sinT * cosf(phi), sinT * sinf(phi), cosT));
 }
+/* Extension (no reference counterpart): Russian roulette on the path throughput. Returns 0 when the path is
+ * cut; otherwise rescales *weight and stores the new throughput in the child's state. */
+static int roulette(rng_t* g, rng_t* child, v3* weight)
+{
+    v3 thr = mul3(g->thr, *weight);
+    if ((g->flags & PO_FLAG_RUSSIAN_ROULETTE) && g->bounce + 1 >= 3) {
+        float q = clampr(fmaxr(fmaxr(thr.x, thr.y), thr.z), 0.05f, 1.0f);
+        if (!(po_rand01(g->key, g->bounce, 7) < q)) return 0;
+        float iq = 1.0f / q;
+        *weight = scl3(*weight, iq);
+        thr = scl3(thr, iq);
+    }
+    child->thr = thr;
+    return 1;
+}
 static v3 trace_ray(const po_scene* s, ray_t ray, int depth, int albedoOnly, rng_t* g)
 {
     if (depth <= 0) return V3(0, 0, 0);
@@ -786,7 +826,7 @@ static v3 trace_ray(const po_scene* s, ray_t ray, int depth, int albedoOnly, rng
     const float kTMin = 1e-4f;
     hit_t best; memset(&best, 0, sizeof best);
     float closestT;
-    if (!closest_hit(s, &ray, &best, &closestT)) return s->background;
+    if (!closest_hit(s, &ray, &best, &closestT)) return s->sky ? sky_lookup(s, ray.d) : s->background;
     const po_material* m = &best.mat;
     v3 albedo = V3(m->albedo[0], m->albedo[1], m->albedo[2]);
     if (albedoOnly) { /* PathTracer.cpp:62-71 */
@@ -809,7 +849,7 @@ static v3 trace_ray(const po_scene* s, ray_t ray, int depth, int albedoOnly, rng
                0.04f * (1.0f - m->metallic) + albedo.z * m->metallic);
     float roughness = clampr(m->roughness, 0.0f, 1.0f);
     float alpha = fmaxr(1e-4f, roughness * roughness);
-    rng_t child = { g->key, g->bounce + 1, 0 };
+    rng_t child = { g->key, g->bounce + 1, 0, g->flags, g->thr };
     const float pT = clampr(m->transmission, 0.0f, 1.0f);
     if (pT > 0.0f && Rand01(g) < pT) { /* PathTracer.cpp:99-204 */
         float eta_i = ray.ior, eta_m = m->ior;
@@ -836,6 +876,7 @@ static v3 trace_ray(const po_scene* s, ray_t ray, int depth, int albedoOnly, rng
             float selPdf = fmaxr(1e-3f, pT * pR);
             weight = div3s(weight, selPdf);
             ray_t next; next.o = add3(best.p, scl3(wi, kTMin)); next.d = wi; next.ior = ray.ior;
+            if (!roulette(g, &child, &weight)) return L;
             L = add3(L, mul3(weight, trace_ray(s, next, depth - 1, 0, &child)));
             return L;
         } else if (!TIR) {
@@ -843,7 +884,9 @@ static v3 trace_ray(const po_scene* s, ray_t ray, int depth, int albedoOnly, rng
             float selPdf = fmaxr(1e-3f, pT * (1.0f - pR));
             float weight = (1.0f - F) / selPdf;
             ray_t next; next.o = add3(best.p, scl3(tdir, kTMin)); next.d = tdir; next.ior = eta_t;
-            L = add3(L, scl3(trace_ray(s, next, depth - 1, 0, &child), weight));
+            v3 w3 = V3(weight, weight, weight);
+            if (!roulette(g, &child, &w3)) return L;
+            L = add3(L, mul3(w3, trace_ray(s, next, depth - 1, 0, &child)));
             return L;
         }
     }
@@ -865,6 +908,7 @@ static v3 trace_ray(const po_scene* s, ray_t ray, int depth, int albedoOnly, rng
         weight = div3s(weight, fmaxr(1e-3f, specProb));
         weight = div3s(weight, fmaxr(1e-3f, 1.0f - pT));
         ray_t next; next.o = add3(best.p, scl3(n, kTMin)); next.d = wi; next.ior = 1.0f;
+        if (!roulette(g, &child, &weight)) return L;
         L = add3(L, mul3(weight, trace_ray(s, next, depth - 1, 0, &child)));
     } else { /* PathTracer.cpp:284-300 */
         v3 dl = sample_cos_hemi(g);
@@ -872,18 +916,19 @@ static v3 trace_ray(const po_scene* s, ray_t ray, int depth, int albedoOnly, rng
         ray_t next; next.o = add3(best.p, scl3(n, kTMin)); next.d = dw; next.ior = 1.0f;
         v3 weight = div3s(scl3(albedo, 1.0f - m->metallic), fmaxr(1e-3f, 1.0f - specProb));
         weight = div3s(weight, fmaxr(1e-3f, 1.0f - pT));
+        if (!roulette(g, &child, &weight)) return L;
         L = add3(L, mul3(weight, trace_ray(s, next, depth - 1, 0, &child)));
     }
     return L;
 }
 
 static void trace_sample(const po_scene* s, const cam_state* cs, int w, int h, int x, int y, uint32_t sample,
-                         int depth, int albedo_only, uint32_t seed, float rgb[3])
+                         int depth, int albedo_only, uint32_t seed, uint32_t flags, float rgb[3])
 {
     float rr[6];
     camera_ray(cs, x, y, w, h, rr);
     ray_t ray; ray.o = V3(rr[0], rr[1], rr[2]); ray.d = V3(rr[3], rr[4], rr[5]); ray.ior = 1.0f;
-    rng_t g = { po_path_key(seed, (uint32_t)(y * w + x), sample), 0, 0 };
+    rng_t g = { po_path_key(seed, (uint32_t)(y * w + x), sample), 0, 0, flags, { 1.0f, 1.0f, 1.0f } };
     if (g_cnt) g_cnt->samples++;
     v3 c = trace_ray(s, ray, depth, albedo_only, &g);
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
@@ -892,7 +937,7 @@ void po_trace_sample(const po_scene* s, const po_camera* cam, int w, int h, int 
                      int depth, int albedo_only, uint32_t seed, float rgb[3])
 {
     cam_state cs = camera_prepare(cam, w, h);
-    trace_sample(s, &cs, w, h, x, y, sample, depth, albedo_only, seed, rgb);
+    trace_sample(s, &cs, w, h, x, y, sample, depth, albedo_only, seed, 0u, rgb);
 }
 
 /* ------------------------------------------------------------------ film (Film.cpp:34-104) */
@@ -929,7 +974,7 @@ void po_film_resolve(const float* accum, const uint32_t* samples, int n, int ton
 /* ------------------------------------------------------------------ frame driver (main.cpp:17-47) */
 typedef struct {
     const po_scene* s; cam_state cs; int w, h; float* accum; uint32_t* samples;
-    uint32_t spp_begin, spp_count; int depth, albedo_only; uint32_t seed; int x0, y0, x1, y1;
+    uint32_t spp_begin, spp_count; int depth, albedo_only; uint32_t seed, flags; int x0, y0, x1, y1;
     int next_row; pthread_mutex_t mu; po_counters total; int want_counters;
 } job_t;
 static void* worker(void* arg)
@@ -947,7 +992,7 @@ static void* worker(void* arg)
             /* one pixel's samples in index order: the same add order as spp successive frame passes */
             for (uint32_t k = 0; k < j->spp_count; ++k) {
                 float rgb[3];
-                trace_sample(j->s, &j->cs, j->w, j->h, x, y, j->spp_begin + k, j->depth, j->albedo_only, j->seed, rgb);
+                trace_sample(j->s, &j->cs, j->w, j->h, x, y, j->spp_begin + k, j->depth, j->albedo_only, j->seed, j->flags, rgb);
                 po_film_add_sample(&j->accum[3 * p], &j->samples[p], rgb);
             }
         }
@@ -965,7 +1010,14 @@ void po_render(const po_scene* s, const po_camera* cam, int w, int h, float* acc
                uint32_t spp_begin, uint32_t spp_count, int depth, int albedo_only, uint32_t seed,
                int x0, int y0, int x1, int y1, int nthreads, po_counters* counters)
 {
+    po_render_ext(s, cam, w, h, accum, samples, spp_begin, spp_count, depth, albedo_only, seed, x0, y0, x1, y1, nthreads, counters, 0u);
+}
+void po_render_ext(const po_scene* s, const po_camera* cam, int w, int h, float* accum, uint32_t* samples,
+                   uint32_t spp_begin, uint32_t spp_count, int depth, int albedo_only, uint32_t seed,
+                   int x0, int y0, int x1, int y1, int nthreads, po_counters* counters, uint32_t flags)
+{
     job_t j; memset(&j, 0, sizeof j);
+    j.flags = flags;
     j.s = s; j.cs = camera_prepare(cam, w, h); j.w = w; j.h = h; j.accum = accum; j.samples = samples;
     j.spp_begin = spp_begin; j.spp_count = spp_count; j.depth = depth; j.albedo_only = albedo_only; j.seed = seed;
     j.x0 = x0 < 0 ? 0 : x0; j.y0 = y0 < 0 ? 0 : y0; j.x1 = x1 > w ? w : x1; j.y1 = y1 > h ? h : y1;

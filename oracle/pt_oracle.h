@@ -104,6 +104,20 @@ void po_render(const po_scene*, const po_camera*, int w, int h, float* accum, ui
                uint32_t spp_begin, uint32_t spp_count, int depth, int albedo_only, uint32_t seed,
                int x0, int y0, int x1, int y1, int nthreads, po_counters* counters);
 
+/* ---- extensions with NO counterpart in the reference (it has no skybox code and no Russian roulette; both are
+ * off unless asked for). They exist so that the GPU implementation of the same extensions can be checked
+ * sample for sample; their own correctness is tested analytically (uniform cubemap == constant background,
+ * roulette leaves the expected image unchanged). */
+#define PO_FLAG_RUSSIAN_ROULETTE 2u
+/* Cubemap: 6 faces (+x, -x, +y, -y, +z, -z), each size x size RGBA8, row 0 = top; OpenGL face orientation,
+ * nearest texel, texel / 255 * intensity replaces the constant miss radiance. faces == NULL disables it. */
+void po_scene_set_skybox(po_scene*, int size, const uint8_t* const faces[6], float intensity);
+/* po_render with flags (PO_FLAG_RUSSIAN_ROULETTE: from the 3rd bounce on a path survives with probability
+ * q = clamp(max(throughput), 0.05, 1) drawn from slot 7 of the bounce's random numbers, and is divided by q). */
+void po_render_ext(const po_scene*, const po_camera*, int w, int h, float* accum, uint32_t* samples,
+                   uint32_t spp_begin, uint32_t spp_count, int depth, int albedo_only, uint32_t seed,
+                   int x0, int y0, int x1, int y1, int nthreads, po_counters* counters, uint32_t flags);
+
 /* Film::AddSample (Film.cpp:34-46) on one pixel. */
 void po_film_add_sample(float accum_px[3], uint32_t* samples_px, const float rgb[3]);
 /* Film::ResolveToRGBA8 (Film.cpp:55-104). tonemap: 0 none, 1 Reinhard; colourspace: 0 linear, 1 sRGB. */

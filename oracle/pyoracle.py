@@ -72,6 +72,8 @@ def lib():
         L.po_trace_sample.argtypes = [C.c_void_p, C.POINTER(Camera)] + [C.c_int] * 4 + [C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float)]
         L.po_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32] + [C.c_int] * 5 + [C.POINTER(Counters)]
+        L.po_render_ext.argtypes = L.po_render.argtypes + [C.c_uint32]
+        L.po_scene_set_skybox.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_float]
         L.po_film_add_sample.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         L.po_film_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.po_pcg_hash.argtypes = [C.c_uint32]
@@ -148,6 +150,17 @@ class Scene:
                 raise ValueError(o["type"])
         self.cam = make_camera(scene["camera"])
         self.w, self.h_px = scene["film"]
+        if scene.get("skybox") is not None:
+            self.set_skybox(scene["skybox"]["faces"], scene["skybox"].get("intensity", 1.0))
+
+    def set_skybox(self, faces, intensity=1.0):
+        """Extension (no reference counterpart): faces = (6, N, N, 4) uint8 in +x -x +y -y +z -z order, or None."""
+        if faces is None:
+            lib().po_scene_set_skybox(self.h, 0, None, 0.0)
+            return
+        f = np.ascontiguousarray(faces, np.uint8)
+        ptrs = (C.c_void_p * 6)(*[f[i].ctypes.data for i in range(6)])
+        lib().po_scene_set_skybox(self.h, f.shape[1], ptrs, float(intensity))
 
     def add_mesh(self, md, pos, rot, scale):
         L = lib()
@@ -194,16 +207,16 @@ class Scene:
         return out
 
     def render(self, spp, depth, albedo_only=False, seed=0x5EED, spp_begin=0, rect=None, threads=None,
-               accum=None, samples=None, counters=False):
+               accum=None, samples=None, counters=False, russian_roulette=False):
         w, h = self.w, self.h_px
         if accum is None:
             accum = np.zeros((h, w, 3), np.float32)
             samples = np.zeros((h, w), np.uint32)
         x0, y0, x1, y1 = rect if rect else (0, 0, w, h)
         cnt = Counters()
-        lib().po_render(self.h, C.byref(self.cam), w, h, accum.ctypes.data, samples.ctypes.data, spp_begin, spp,
-                        depth, int(albedo_only), seed, x0, y0, x1, y1, threads or os.cpu_count() or 1,
-                        C.byref(cnt) if counters else None)
+        lib().po_render_ext(self.h, C.byref(self.cam), w, h, accum.ctypes.data, samples.ctypes.data, spp_begin, spp,
+                            depth, int(albedo_only), seed, x0, y0, x1, y1, threads or os.cpu_count() or 1,
+                            C.byref(cnt) if counters else None, 2 if russian_roulette else 0)
         if counters:
             return accum, samples, cnt.as_dict()
         return accum, samples

@@ -552,4 +552,22 @@ PT_DEV Ray camera_ray(const DCamera& cam, int px, int py)
     return ray;
 }
 
+// Miss radiance from the cubemap (an extension: the reference only has the constant of PathTracer.h:21).
+// OpenGL face selection and orientation, nearest texel, texel / 255 * intensity, no sRGB decode.
+PT_DEV f3 sky_lookup(const DScene& sc, f3 d)
+{
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int face; float s, t, ma;
+    if (ax >= ay && ax >= az) { ma = ax; if (d.x > 0.f) { face = 0; s = -d.z; t = -d.y; } else { face = 1; s = d.z; t = -d.y; } }
+    else if (ay >= az) { ma = ay; if (d.y > 0.f) { face = 2; s = d.x; t = d.z; } else { face = 3; s = d.x; t = -d.z; } }
+    else { ma = az; if (d.z > 0.f) { face = 4; s = d.x; t = -d.y; } else { face = 5; s = -d.x; t = -d.y; } }
+    float u = (__fdiv_rn(s, ma) + 1.0f) * 0.5f, v = (__fdiv_rn(t, ma) + 1.0f) * 0.5f;
+    const int n = sc.sky_size;
+    int x = (int)(u * (float)n), y = (int)(v * (float)n);
+    x = min(max(x, 0), n - 1); y = min(max(y, 0), n - 1);
+    uint32_t px = sc.sky[((size_t)face * n + y) * n + x];
+    f3 c = mk3(__fdiv_rn((float)(px & 255u), 255.0f), __fdiv_rn((float)((px >> 8) & 255u), 255.0f), __fdiv_rn((float)((px >> 16) & 255u), 255.0f));
+    return c * sc.sky_intensity;
+}
+
 } // namespace ptamd

@@ -86,8 +86,9 @@ struct ptamd_scene {
     DevBuf<DObject> d_objects; DevBuf<DMesh> d_meshes; DevBuf<DMaterial> d_materials;
     DevBuf<DNode> d_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
+    DevBuf<uint32_t> d_sky; int sky_size = 0; float sky_intensity = 1.0f;
     DScene dscene;
-    void release()
+    void release() // what commit rebuilds; the sky map is uploaded by its own call and outlives commits
     {
         d_objects.release(); d_meshes.release(); d_materials.release(); d_nodes.release(); d_tris.release();
         d_shade.release(); d_groups.release(); d_images.release(); d_texels.release();
@@ -266,7 +267,7 @@ int ptamd_scene_create(ptamd_scene** out)
 int ptamd_scene_destroy(ptamd_scene* s)
 {
     if (!s) return PTAMD_OK;
-    s->release();
+    s->release(); s->d_sky.release();
     delete s;
     return PTAMD_OK;
 }
@@ -370,6 +371,26 @@ int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3])
     if (!rgb) return fail(PTAMD_ERR_ARG, "null colour");
     std::memcpy(s->background, rgb, 12);
     if (s->committed) std::memcpy(s->dscene.background, rgb, 12);
+    return PTAMD_OK;
+}
+
+int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const faces[6], float intensity)
+{
+    if (int rc = check_scene(s)) return rc;
+    if (!faces || face_size <= 0) {
+        s->d_sky.release(); s->sky_size = 0;
+        s->dscene.sky = nullptr; s->dscene.sky_size = 0;
+        return PTAMD_OK;
+    }
+    if (int rc = need_init()) return rc;
+    if (face_size > 8192) return fail(PTAMD_ERR_LIMIT, "skybox faces are limited to 8192 x 8192");
+    for (int f = 0; f < 6; ++f) if (!faces[f]) return fail(PTAMD_ERR_ARG, "null skybox face");
+    const size_t n = (size_t)face_size * face_size;
+    std::vector<uint32_t> tex(6 * n);
+    for (int f = 0; f < 6; ++f) std::memcpy(tex.data() + f * n, faces[f], n * 4);
+    if (int rc = s->d_sky.upload(tex)) return rc;
+    s->sky_size = face_size; s->sky_intensity = intensity;
+    s->dscene.sky = s->d_sky.ptr; s->dscene.sky_size = face_size; s->dscene.sky_intensity = intensity;
     return PTAMD_OK;
 }
 
@@ -489,6 +510,7 @@ int ptamd_scene_commit(ptamd_scene* s)
     ds.shade = reinterpret_cast<const float4*>(s->d_shade.ptr);
     ds.groups = s->d_groups.ptr; ds.images = s->d_images.ptr; ds.texels = s->d_texels.ptr;
     std::memcpy(ds.background, s->background, 12);
+    ds.sky = s->sky_size ? s->d_sky.ptr : nullptr; ds.sky_size = s->sky_size; ds.sky_intensity = s->sky_intensity;
     ds.num_nodes = (uint32_t)nodes.size(); ds.num_tris = (uint32_t)tris.size();
     ds.max_stack = 1;
     for (const HostObject& ho : s->objects) if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, ho.mesh->bvh.depth);
@@ -639,6 +661,7 @@ int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_
     if (int rc = need_init()) return rc;
     if (!s->committed) return fail(PTAMD_ERR_STATE, "scene has uncommitted edits: call ptamd_scene_commit first");
     if (f->w <= 0 || f->h <= 0) return fail(PTAMD_ERR_STATE, "film has no pixels");
+    if (s->dscene.sky_size > 0 && !s->dscene.sky) return fail(PTAMD_ERR_STATE, "sky map has no device buffer");
     if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(PTAMD_ERR_ARG, "sample index range overflows 32 bits");
     DRenderParams rp; std::memset(&rp, 0, sizeof rp);
     rp.cam = make_camera(*cam, f->w, f->h);

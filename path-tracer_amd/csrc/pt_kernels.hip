@@ -46,7 +46,10 @@ PT_DEV void add_sample(f3& acc, f3 c)
 // throughput scales almost linearly with resident waves up to 5 per SIMD; asking for 5 holds the register
 // allocator to 96 VGPRs, which it meets without spilling. 6 (80 VGPRs) and 8 (64) spill into the loop and lose.
 // COUNT: also tally rays, BVH node visits and triangle tests (PTAMD_FLAG_COUNT); kept out of the timed build.
-template <int STACK, bool LDS_GEOM, bool COUNT>
+// EXT: the two options the reference does not have, Russian roulette and the cubemap sky; a build of its own so
+// that the default kernel carries neither their registers nor their branches.
+constexpr uint32_t kFlagRoulette = 2u; // PTAMD_FLAG_RUSSIAN_ROULETTE
+template <int STACK, bool LDS_GEOM, bool COUNT, bool EXT>
 __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderParams rp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderPar
         }
         bool done;
         if (best.obj < 0) {
-            L = L + T * bg;                       // PathTracer.cpp:59-60
+            L = L + T * ((EXT && sc.sky_size > 0) ? sky_lookup(sc, ray.d) : bg); // PathTracer.cpp:59-60
             done = true;
         } else {
             HitInfo h;
@@ -114,6 +117,12 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderPar
                     f3 w;
                     done = !sample_bsdf(h, ray, ior, w, key, (uint32_t)bounce);
                     T = T * w;
+                    if (EXT && (rp.flags & kFlagRoulette) && bounce + 1 >= 3 && !done) {
+                        // survive with probability q = clamp(max T, 0.05, 1), drawn from slot 7 of this bounce
+                        float q = clampf(fmaxf(fmaxf(T.x, T.y), T.z), 0.05f, 1.0f);
+                        if (!(rand01(key, (uint32_t)bounce, 7u) < q)) done = true;
+                        else T = T * __fdiv_rn(1.0f, q);
+                    }
                     ++bounce;
                 }
             }
@@ -231,10 +240,13 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const size_t geomBytes = fits ? (size_t)geomF4 * 16 : 0;
     auto lds = [&](int stack) { return ((size_t)stack * sizeof(StackEntry) + 12) * kBlock + geomBytes; };
     const bool count = rp.counters != nullptr;
+    const bool ext = (rp.flags & kFlagRoulette) != 0 || sc.sky_size > 0;
 #define PT_LAUNCH(STACK, LDSG)                                                                                        \
     do {                                                                                                              \
-        if (count) hipLaunchKernelGGL((render_kernel<STACK, LDSG, true>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp); \
-        else hipLaunchKernelGGL((render_kernel<STACK, LDSG, false>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);     \
+        if (count && ext) hipLaunchKernelGGL((render_kernel<STACK, LDSG, true, true>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);  \
+        else if (count) hipLaunchKernelGGL((render_kernel<STACK, LDSG, true, false>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);   \
+        else if (ext) hipLaunchKernelGGL((render_kernel<STACK, LDSG, false, true>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);     \
+        else hipLaunchKernelGGL((render_kernel<STACK, LDSG, false, false>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);             \
     } while (0)
     if (fits && sc.max_stack <= 8) PT_LAUNCH(8, true);
     else if (fits && sc.max_stack <= 16) PT_LAUNCH(16, true);

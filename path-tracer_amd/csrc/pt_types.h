@@ -96,7 +96,8 @@ struct DScene {
     const uint8_t* texels;
     float background[3]; int32_t pad;
     uint32_t num_nodes, num_tris; // totals over all meshes (what an LDS-staged copy holds)
-    uint32_t pad1, pad2;
+    int32_t sky_size; float sky_intensity; // cubemap miss radiance (no reference counterpart): 0 = constant background
+    const uint32_t* sky;   // 6 faces (+x -x +y -y +z -z) of sky_size^2 RGBA8 texels, row 0 = top
 };
 
 // Camera matrices as Camera::CalculateMatrices leaves them (Camera.cpp:22-35), glm column-major.
@@ -114,7 +115,7 @@ struct DRenderParams {
     int32_t x0, y0, x1, y1;
     uint32_t spp_begin, spp_count;
     int32_t depth, albedo_only;
-    uint32_t seed, flags;
+    uint32_t seed, flags;  // flags: PTAMD_FLAG_* of the public header
     int32_t tiles_x, tiles_y; // 8x8-pixel tiles covering the rect
 };
 

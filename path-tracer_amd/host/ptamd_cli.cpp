@@ -3,12 +3,14 @@
 // through the host classes of ptamd.hpp and saves the image.
 //
 //   ptamd_cli <scene.txt> --out image.png [--spp 64] [--depth 10] [--albedo] [--seed N] [--device D]
-//             [--pfm hdr.pfm] [--raw prefix] [--linear] [--no-tonemap] [--frames]
+//             [--pfm hdr.pfm] [--raw prefix] [--linear] [--no-tonemap] [--frames] [--rr]
 //
 // Scene records (whitespace separated, '#' comments):
 //   film W H | camera px py pz rx ry rz fov [near far] | background r g b
 //   sphere px py pz r <mat> | box px py pz rx ry rz sx sy sz <mat> | mesh path px py pz rx ry rz sx sy sz
 //   <mat> = albedo(3) roughness metallic emissionColour(3) emissionStrength IOR transmission
+//   skybox file.rgba8 N intensity   (6 faces of N x N RGBA8, +x -x +y -y +z -z; not a feature of the reference)
+// --rr turns Russian roulette on (also not in the reference; off by default).
 // --frames renders one sample per pixel per launch, as the reference's main loop does (main.cpp:565-569);
 // the default renders all samples in one launch. Both give the same image bit for bit.
 #include <chrono>
@@ -18,6 +20,7 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <vector>
 
 #include "image_io.hpp"
 #include "ptamd.hpp"
@@ -35,13 +38,13 @@ static Material ReadMaterial(std::istream& in)
 int main(int argc, char** argv)
 {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: ptamd_cli <scene.txt> --out image.png [--spp N] [--depth D] [--albedo] [--seed S] [--device I] [--pfm f] [--raw prefix] [--linear] [--no-tonemap] [--frames]\n");
+        std::fprintf(stderr, "usage: ptamd_cli <scene.txt> --out image.png [--spp N] [--depth D] [--albedo] [--seed S] [--device I] [--pfm f] [--raw prefix] [--linear] [--no-tonemap] [--frames] [--rr]\n");
         return 2;
     }
     std::string scenePath = argv[1], outPng, outPfm, outRaw;
     int spp = 64, depth = 10, device = 0;
     uint32_t seed = 0x5EED;
-    bool albedo = false, linear = false, noTonemap = false, frames = false;
+    bool albedo = false, linear = false, noTonemap = false, frames = false, roulette = false;
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -56,6 +59,7 @@ int main(int argc, char** argv)
         else if (a == "--linear") linear = true;
         else if (a == "--no-tonemap") noTonemap = true;
         else if (a == "--frames") frames = true;
+        else if (a == "--rr") roulette = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     try {
@@ -80,6 +84,15 @@ int main(int argc, char** argv)
                 if (in >> n >> fr) { camera.SetNearPlane(n); camera.SetFarPlane(fr); }
             } else if (kind == "background") {
                 vec3 c; in >> c.x >> c.y >> c.z; pathTracer.SetBackgroundColour(c);
+            } else if (kind == "skybox") {
+                std::string sp; int n = 0; float intensity = 1.0f; in >> sp >> n >> intensity;
+                if (n <= 0) throw std::runtime_error("skybox: bad face size");
+                std::ifstream sf(sp, std::ios::binary);
+                std::vector<uint8_t> texels(size_t(6) * n * n * 4);
+                if (!sf || !sf.read(reinterpret_cast<char*>(texels.data()), (std::streamsize)texels.size())) throw std::runtime_error("skybox: cannot read " + sp);
+                const uint8_t* faces[6];
+                for (int k = 0; k < 6; ++k) faces[k] = texels.data() + size_t(k) * n * n * 4;
+                pathTracer.SetSkybox(n, faces, intensity);
             } else if (kind == "sphere") {
                 vec3 p; float r; in >> p.x >> p.y >> p.z >> r;
                 auto o = std::make_shared<Sphere>("Sphere", p, r);
@@ -104,8 +117,9 @@ int main(int argc, char** argv)
         if (linear) film.SetColourSpace(ColourSpace::Linear);
         if (noTonemap) film.SetToneMap(ToneMap::None);
         t0 = std::chrono::steady_clock::now();
-        if (frames) for (int i = 0; i < spp; ++i) RayTraceParallel(ivec2(W, H), camera, pathTracer, film, depth, albedo, (uint32_t)i, seed);
-        else Render(camera, pathTracer, film, 0, (uint32_t)spp, depth, albedo, seed);
+        const uint32_t flags = roulette ? PTAMD_FLAG_RUSSIAN_ROULETTE : 0u;
+        if (frames) for (int i = 0; i < spp; ++i) Render(camera, pathTracer, film, (uint32_t)i, 1, depth, albedo, seed, nullptr, flags); // = RayTraceParallel per frame
+        else Render(camera, pathTracer, film, 0, (uint32_t)spp, depth, albedo, seed, nullptr, flags);
         check(ptamd_synchronize());
         double renderS = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (!outPng.empty() && !SaveImagePNG(outPng, W, H, film.ResolveToRGBA8())) throw std::runtime_error("cannot write " + outPng);

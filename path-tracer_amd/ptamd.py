@@ -62,6 +62,7 @@ class CStats(C.Structure):
 
 
 FLAG_COUNT = 1
+FLAG_RUSSIAN_ROULETTE = 2
 
 # every symbol include/ptamd.h declares (tests check that the library exports all of them)
 EXPORTS = [
@@ -69,7 +70,7 @@ EXPORTS = [
     "ptamd_pbr_default", "ptamd_scene_create", "ptamd_scene_destroy", "ptamd_scene_clear",
     "ptamd_scene_object_count", "ptamd_scene_add_sphere", "ptamd_scene_add_box", "ptamd_scene_add_mesh",
     "ptamd_scene_add_mesh_file", "ptamd_scene_set_transform", "ptamd_scene_set_radius",
-    "ptamd_scene_set_material", "ptamd_scene_set_mesh_group", "ptamd_scene_set_background",
+    "ptamd_scene_set_material", "ptamd_scene_set_mesh_group", "ptamd_scene_set_background", "ptamd_scene_set_skybox",
     "ptamd_scene_commit", "ptamd_model_load", "ptamd_model_desc", "ptamd_model_group_name", "ptamd_model_free",
     "ptamd_film_create", "ptamd_film_create_external", "ptamd_film_destroy", "ptamd_film_resize",
     "ptamd_film_reset", "ptamd_film_size", "ptamd_film_read", "ptamd_film_average",
@@ -114,6 +115,7 @@ def lib():
         L.ptamd_scene_set_material.argtypes = [vp, C.c_int, C.POINTER(CMaterial)]
         L.ptamd_scene_set_mesh_group.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(CPbr)]
         L.ptamd_scene_set_background.argtypes = [vp, f3]
+        L.ptamd_scene_set_skybox.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.c_float]
         L.ptamd_scene_commit.argtypes = [vp]
         L.ptamd_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.ptamd_model_desc.argtypes = [vp, C.POINTER(CMeshDesc)]
@@ -362,6 +364,18 @@ class PathTracer:
     def SetBackgroundColour(self, rgb):
         check(lib().ptamd_scene_set_background(self._h, _f3(rgb)))
 
+    def SetSkybox(self, faces, intensity=1.0):
+        """Cubemap miss radiance (the reference has only the constant background): faces is a (6, N, N, 4) uint8
+        array in +x -x +y -y +z -z order, row 0 at the top; None removes it."""
+        if faces is None:
+            check(lib().ptamd_scene_set_skybox(self._h, 0, None, 0.0))
+            return
+        f = np.ascontiguousarray(faces, np.uint8)
+        if f.ndim != 4 or f.shape[0] != 6 or f.shape[1] != f.shape[2] or f.shape[3] != 4:
+            raise ValueError("skybox faces must be (6, N, N, 4) uint8")
+        ptrs = (C.c_void_p * 6)(*[f[i].ctypes.data for i in range(6)])
+        check(lib().ptamd_scene_set_skybox(self._h, f.shape[1], ptrs, float(intensity)))
+
     def Commit(self):
         check(lib().ptamd_scene_commit(self._h))
 
@@ -495,11 +509,14 @@ class Film:
             pass
 
 
-def Render(camera, pathTracer, film, spp_count, depth, albedoOnly=False, spp_begin=0, seed=0x5EED, rect=None, count=False):
-    """spp_count passes of RayTraceParallel in one launch (asynchronous)."""
+def Render(camera, pathTracer, film, spp_count, depth, albedoOnly=False, spp_begin=0, seed=0x5EED, rect=None, count=False,
+           russian_roulette=False):
+    """spp_count passes of RayTraceParallel in one launch (asynchronous). russian_roulette is an option the
+    reference does not have (off: every path runs to `depth` as in PathTracer.cpp:35-36)."""
     r = CRect(*rect) if rect is not None else None
+    flags = (FLAG_COUNT if count else 0) | (FLAG_RUSSIAN_ROULETTE if russian_roulette else 0)
     check(lib().ptamd_render(pathTracer._h, C.byref(camera.to_c()), film._h, spp_begin, spp_count, depth,
-                             int(bool(albedoOnly)), seed, C.byref(r) if r is not None else None, FLAG_COUNT if count else 0))
+                             int(bool(albedoOnly)), seed, C.byref(r) if r is not None else None, flags))
 
 
 def RayTraceParallel(winSize, camera, pathTracer, film, depth, albedoOnly, frame=0, seed=0x5EED):
@@ -538,6 +555,8 @@ def build_scene(scene, mesh_data=None):
             raise ValueError(o["type"])
     if "background" in scene:
         pt.SetBackgroundColour(scene["background"])
+    if scene.get("skybox") is not None:
+        pt.SetSkybox(scene["skybox"]["faces"], scene["skybox"].get("intensity", 1.0))
     pt.Commit()
     c = scene["camera"]
     cam = Camera(scene["film"], c["pos"], c["rot"])

@@ -46,3 +46,22 @@ def test_cli_reports_loader_errors(gpu, tmp_path):
     sp.write_text("film 8 8\ncamera 0 0 0 0 0 0 45\nmesh /nonexistent/model.glb 0 0 0 0 0 0 1 1 1\n")
     out = subprocess.run([CLI, str(sp), "--out", str(tmp_path / "x.png")], capture_output=True, text=True)
     assert out.returncode == 1 and "Failed to load GLTF model" in out.stderr
+
+
+def test_cli_skybox_and_roulette(gpu, tmp_path):
+    """The two options outside the reference reach the C++ host classes: `skybox` scene record and --rr."""
+    from test_extensions import gradient_faces
+    scene = presets.glass_mirror(64, 48)
+    faces = gradient_faces(16, seed=3)
+    sp = str(tmp_path / "scene.txt")
+    presets.write_scene_txt(scene, sp)
+    faces.tofile(str(tmp_path / "sky.rgba8"))
+    with open(sp, "a") as f:
+        f.write("skybox %s 16 0.75\n" % (tmp_path / "sky.rgba8"))
+    pt, cam = gpu.build_scene(dict(scene, skybox={"faces": faces, "intensity": 0.75}))
+    film = gpu.Film(64, 48)
+    gpu.Render(cam, pt, film, 3, 9, seed=12, russian_roulette=True)
+    subprocess.run([CLI, sp, "--raw", str(tmp_path / "raw"), "--spp", "3", "--depth", "9", "--seed", "12", "--rr"],
+                   check=True, capture_output=True, text=True, cwd=ROOT)
+    a = np.fromfile(str(tmp_path / "raw.accum.f32"), np.float32).reshape(48, 64, 3)
+    assert np.array_equal(a.view(np.uint32), film.Accum().view(np.uint32))
