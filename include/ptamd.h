@@ -87,6 +87,10 @@ typedef struct ptamd_stats {
     uint64_t rays;    /* rays cast, primary + bounces */
     uint64_t nodes;   /* BVH inner-node visits (each tests both child boxes) */
     uint64_t tris;    /* ray-triangle tests */
+    /* Wave-level loop trips (64 lanes issue together): lanes-per-trip = rays / ray_trips, nodes / node_trips,
+     * tris / tri_trips, shade_lanes / shade_trips is how full the wave was in that loop. */
+    uint64_t ray_trips, node_trips, tri_trips;
+    uint64_t shade_lanes, shade_trips; /* hits shaded, and wave-level passes through the shading block */
 } ptamd_stats;
 
 typedef struct ptamd_scene ptamd_scene;

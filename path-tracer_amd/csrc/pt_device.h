@@ -197,7 +197,10 @@ struct Geom { const float4* nodes; const float4* tris; uint32_t node_stride, nod
 // `slot` of a [depth][BLOCK] array, so a wave's pushes and pops hit 64 different banks). A popped inner node
 // that has fallen behind the closest hit costs one visit (both child tests fail against closestT); storing
 // entry distances to drop such entries on pop was measured slower (8-byte stack traffic, more LDS per block).
-struct TraversalCounts { uint32_t nodes, tris; };
+// nodes / tris: per-lane work. node_trips / tri_trips: loop trips the whole wave paid for (counted by the first
+// active lane of each trip), so lanes-per-trip = nodes / node_trips is the lane utilisation of that loop.
+struct TraversalCounts { uint32_t nodes, tris, node_trips, tri_trips; };
+PT_DEV bool wave_leader() { return (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1; }
 typedef uint32_t StackEntry;
 
 template <int BLOCK, bool COUNT>
@@ -218,7 +221,7 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
     };
     while (cur != kDone) {
         while ((uint32_t)cur < (uint32_t)kDone) { // inner node
-            if (COUNT) ++cnt.nodes;
+            if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
             const float4* n = nodes + (size_t)cur * nstep;
             float4 a = n[0], b = n[ns], c = n[2 * ns], r = n[3 * ns];
             float lx0 = fmaf(a.x, inv.x, -oi.x), lx1 = fmaf(a.w, inv.x, -oi.x);
@@ -248,7 +251,7 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
             uint32_t code = ~(uint32_t)cur;
             uint32_t first = code >> 3, cnt_tris = (code & 7u) + 1u;
             for (uint32_t i = 0; i < cnt_tris; ++i) {
-                if (COUNT) ++cnt.tris;
+                if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
                 float t, u, v; int group;
                 if (!tri_test(tris + (size_t)(first + i) * tstep, ts, o, d, t, u, v, group)) continue;
                 if (t < tMinObj || t >= closestT) continue; // Mesh.cpp:104
@@ -264,7 +267,7 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
 template <int BLOCK, bool COUNT = false>
 PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, StackEntry* __restrict__ stack, int slot, TraversalCounts* counts = nullptr)
 {
-    TraversalCounts cnt; cnt.nodes = 0; cnt.tris = 0;
+    TraversalCounts cnt; cnt.nodes = 0; cnt.tris = 0; cnt.node_trips = 0; cnt.tri_trips = 0;
     const float kTMin = 1e-4f, kTMax = 1e30f;
     Best best; best.t = kTMax; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
     for (int i = 0; i < sc.num_objects; ++i) {
@@ -355,18 +358,22 @@ PT_DEV void fill_material_textured(const DScene& sc, const DPbr& g, float u, flo
 // Rebuilds the Hit of the winning object: Sphere.cpp:55-68, Box.cpp:56-89, Mesh.cpp:153-254.
 PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo& h)
 {
+    // Every branch leaves its results in these locals and `h` is written once, after the branches join: stores
+    // to different fields at the ends of the branches get merged by the compiler into stores through a selected
+    // address, which forces those fields into scratch memory.
     const DObject& ob = sc.objects[best.obj];
+    f3 p, n; bool frontFace;
+    int matIndex = -1;
+    if (ob.kind != KIND_MESH) load_material(sc, ob.material, h); // issued first: the loads overlap the normal computation
     if (ob.kind == KIND_SPHERE) {
-        h.p = ray.o + ray.d * best.t;
-        f3 outward = (h.p - mk3(ob.c[0], ob.c[1], ob.c[2])) * frcp(ob.radius);
-        h.frontFace = dot(ray.d, outward) < 0.0f;
-        h.n = h.frontFace ? outward : -outward;
-        load_material(sc, ob.material, h);
+        p = ray.o + ray.d * best.t;
+        f3 outward = (p - mk3(ob.c[0], ob.c[1], ob.c[2])) * frcp(ob.radius);
+        frontFace = dot(ray.d, outward) < 0.0f;
+        n = frontFace ? outward : -outward;
     } else if (ob.kind == KIND_BOX) {
-        h.p = ray.o + ray.d * best.t;
-        h.n = box_normal(ob, ray, best.t);
-        h.frontFace = false; // Box never reports a front face (Box.cpp:86-89 with PathTracer.cpp:47)
-        load_material(sc, ob.material, h);
+        p = ray.o + ray.d * best.t;
+        n = box_normal(ob, ray, best.t);
+        frontFace = false; // Box never reports a front face (Box.cpp:86-89 with PathTracer.cpp:47)
     } else {
         const DMesh& me = sc.meshes[ob.mesh];
         const float4* s = sc.shade + ((size_t)me.tri_base + (size_t)best.tri) * 7;
@@ -379,8 +386,8 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
         f3 nObjG = normalize(cross(pb - pa, pc - pa));
         float tu = w * s4.z + u * s5.x + v * s5.z, tv = w * s4.w + u * s5.y + v * s5.w;
         int group = __float_as_int(s6.x);
-        h.p = xform_point(me.m, pObj);
-        int matIndex = 0; // slot 0 = Material{} defaults (Mesh.cpp:242-246)
+        p = xform_point(me.m, pObj);
+        matIndex = 0; // slot 0 = Material{} defaults (Mesh.cpp:242-246)
         if (group >= 0) {
             const DPbr& g = sc.groups[me.group_base + group];
             if (g.normal_tex >= 0) { // Mesh.cpp:174-226
@@ -406,12 +413,13 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
             if (textured) fill_material_textured(sc, g, tu, tv, h);
             matIndex = textured ? -1 : g.material; // untextured groups: constant material slot
         }
-        if (matIndex >= 0) load_material(sc, matIndex, h);
         f3 nW = normalize(xform_normal(me.minv, nObj));
         f3 ngW = normalize(xform_normal(me.minv, nObjG));
-        h.frontFace = dot(ray.d, ngW) < 0.0f;
-        h.n = h.frontFace ? nW : -nW;
+        frontFace = dot(ray.d, ngW) < 0.0f;
+        n = frontFace ? nW : -nW;
     }
+    if (matIndex >= 0) load_material(sc, matIndex, h);
+    h.p = p; h.n = n; h.frontFace = frontFace;
 }
 
 // GGX half-vector sample (PathTracer.cpp:125-137, 218-235); the azimuth 2*pi*u1 is taken in turns.

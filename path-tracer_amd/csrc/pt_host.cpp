@@ -33,7 +33,8 @@ thread_local std::string g_error;
 hipStream_t g_own_stream = nullptr;
 hipStream_t g_stream = nullptr;
 bool g_initialised = false;
-unsigned long long* g_counters = nullptr; // device, 4 x u64
+constexpr int kNumCounters = 9;
+unsigned long long* g_counters = nullptr; // device, kNumCounters x u64 (the fields of ptamd_stats)
 
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
 
@@ -233,7 +234,7 @@ int ptamd_init(int device)
     if (device < 0 || device >= n) return fail(PTAMD_ERR_ARG, "device index out of range");
     PT_HIP(hipSetDevice(device));
     if (!g_own_stream) { PT_HIP(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking)); g_stream = g_own_stream; }
-    if (!g_counters) PT_HIP(hipMalloc(reinterpret_cast<void**>(&g_counters), 4 * sizeof(unsigned long long)));
+    if (!g_counters) PT_HIP(hipMalloc(reinterpret_cast<void**>(&g_counters), kNumCounters * sizeof(unsigned long long)));
     g_initialised = true;
     return PTAMD_OK;
 }
@@ -669,7 +670,7 @@ int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_
     rp.x0 = rect ? std::max(0, rect->x0) : 0; rp.y0 = rect ? std::max(0, rect->y0) : 0;
     rp.x1 = rect ? std::min(f->w, rect->x1) : f->w; rp.y1 = rect ? std::min(f->h, rect->y1) : f->h;
     if (flags & PTAMD_FLAG_COUNT) {
-        PT_HIP(hipMemsetAsync(g_counters, 0, 4 * sizeof(unsigned long long), g_stream));
+        PT_HIP(hipMemsetAsync(g_counters, 0, kNumCounters * sizeof(unsigned long long), g_stream));
         rp.counters = g_counters;
     }
     if (rp.x1 <= rp.x0 || rp.y1 <= rp.y0 || spp_count == 0) return PTAMD_OK;
@@ -687,10 +688,11 @@ int ptamd_render_stats(ptamd_stats* out)
 {
     if (!out) return fail(PTAMD_ERR_ARG, "null argument");
     if (int rc = need_init()) return rc;
-    unsigned long long c[4];
+    unsigned long long c[kNumCounters];
     PT_HIP(hipMemcpyAsync(c, g_counters, sizeof c, hipMemcpyDeviceToHost, g_stream));
     PT_HIP(hipStreamSynchronize(g_stream));
     out->samples = c[0]; out->rays = c[1]; out->nodes = c[2]; out->tris = c[3];
+    out->ray_trips = c[4]; out->node_trips = c[5]; out->tri_trips = c[6]; out->shade_lanes = c[7]; out->shade_trips = c[8];
     return PTAMD_OK;
 }
 

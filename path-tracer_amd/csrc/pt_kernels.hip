@@ -6,6 +6,8 @@
 // the next sample, so lanes stay busy although path lengths differ. The film is read once and
 // written once per launch (16 B per pixel), in the reference's sample order.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include "pt_device.h"
 
 namespace ptamd {
@@ -41,7 +43,8 @@ PT_DEV void add_sample(f3& acc, f3 c)
     acc = acc + c;
 }
 
-// Dynamic LDS layout: [STACK][kBlock] traversal stack entries, then (LDS_GEOM) the staged nodes and triangles.
+// Dynamic LDS layout: [rp.stack_depth][kBlock] traversal stack entries (the depth of the scene's deepest tree), [kLaneFloats][kBlock] parked per-lane floats, then
+// (LDS_GEOM) the staged nodes and triangles.
 // Occupancy: the bounce loop is latency bound (dependent VALU chains, LDS and L1 round trips), and its
 // throughput scales almost linearly with resident waves up to 5 per SIMD; asking for 5 holds the register
 // allocator to 96 VGPRs, which it meets without spilling. 6 (80 VGPRs) and 8 (64) spill into the loop and lose.
@@ -49,13 +52,19 @@ PT_DEV void add_sample(f3& acc, f3 c)
 // EXT: the two options the reference does not have, Russian roulette and the cubemap sky; a build of its own so
 // that the default kernel carries neither their registers nor their branches.
 constexpr uint32_t kFlagRoulette = 2u; // PTAMD_FLAG_RUSSIAN_ROULETTE
-template <int STACK, bool LDS_GEOM, bool COUNT, bool EXT>
-__global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderParams rp)
+constexpr int kNumCounters = 9;         // fields of ptamd_stats, in order
+#ifndef PT_WAVES
+#define PT_WAVES 5
+#endif
+constexpr int kLaneFloats = 3;          // per-lane floats parked in LDS: the film sum of the lane's pixel
+template <bool LDS_GEOM, bool COUNT, bool EXT>
+__global__ __launch_bounds__(kBlock, PT_WAVES) void render_kernel(DScene sc, DRenderParams rp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     StackEntry* stack = reinterpret_cast<StackEntry*>(lds_raw);
-    float* lds_acc = reinterpret_cast<float*>(lds_raw + (size_t)STACK * kBlock * sizeof(StackEntry)); // [3][kBlock] film sums
-    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + (size_t)(STACK * sizeof(StackEntry) + 12) * kBlock);
+    const uint32_t stackBytes = (uint32_t)rp.stack_depth * kBlock * (uint32_t)sizeof(StackEntry);
+    float* lds_acc = reinterpret_cast<float*>(lds_raw + stackBytes); // [kLaneFloats][kBlock]
+    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + 4 * kLaneFloats * kBlock);
     const Geom geom = stage_geometry<LDS_GEOM>(sc, lds_geom);
     const int slot = threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -79,15 +88,21 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderPar
         lds_acc[slot] = a0.x; lds_acc[kBlock + slot] = a0.y; lds_acc[2 * kBlock + slot] = a0.z;
     }
 
-    // path state; the primary ray is recomputed for every sample (no jitter: Camera.cpp:47-48) instead of held
+    // Path state. (Parking throughput and radiance in LDS next to the film sum was measured: no gain.) The primary
+    // ray is recomputed for every sample (no jitter: Camera.cpp:47-48) instead of held.
+    f3 Treg, Lreg;
+    auto ldT = [&]() { return Treg; };
+    auto ldL = [&]() { return Lreg; };
+    auto stT = [&](f3 v) { Treg = v; };
+    auto stL = [&](f3 v) { Lreg = v; };
     Ray ray = camera_ray(rp.cam, px, py);
     float ior = 1.0f;
-    f3 T = mk3(1.f, 1.f, 1.f), L = mk3(0.f, 0.f, 0.f);
+    stT(mk3(1.f, 1.f, 1.f)); stL(mk3(0.f, 0.f, 0.f));
     int bounce = 0;
     uint32_t key = path_key(seed_hash, pixel, s);
     uint32_t nrays = 0;
-    TraversalCounts tc_total; tc_total.nodes = 0; tc_total.tris = 0;
-    const f3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
+    TraversalCounts tc_total; tc_total.nodes = 0; tc_total.tris = 0; tc_total.node_trips = 0; tc_total.tri_trips = 0;
+    uint32_t ray_trips = 0, shade_lanes = 0, shade_trips = 0; // wave-level trips of the bounce loop and of its shading block
 
     while (s < s_end) {
         Best best;
@@ -95,15 +110,21 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderPar
             TraversalCounts tc;
             best = closest_hit<kBlock, true>(sc, geom, ray, stack, slot, &tc);
             ++nrays; tc_total.nodes += tc.nodes; tc_total.tris += tc.tris;
+            tc_total.node_trips += tc.node_trips; tc_total.tri_trips += tc.tri_trips;
+            if (wave_leader()) ++ray_trips;
         } else {
             best = closest_hit<kBlock, false>(sc, geom, ray, stack, slot);
         }
         bool done;
+        f3 L = ldL();
+        const f3 T = ldT();
         if (best.obj < 0) {
+            const f3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
             L = L + T * ((EXT && sc.sky_size > 0) ? sky_lookup(sc, ray.d) : bg); // PathTracer.cpp:59-60
             done = true;
         } else {
             HitInfo h;
+            if (COUNT) { ++shade_lanes; if (wave_leader()) ++shade_trips; }
             fill_hit(sc, ray, best, h);
             if (rp.albedo_only && bounce == 0) {  // PathTracer.cpp:62-71 (recursive calls never pass albedoOnly)
                 float dist = clampf(best.t / 20.f, 0.0f, 0.8f);
@@ -116,13 +137,14 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderPar
                 } else {
                     f3 w;
                     done = !sample_bsdf(h, ray, ior, w, key, (uint32_t)bounce);
-                    T = T * w;
+                    f3 Tn = T * w;
                     if (EXT && (rp.flags & kFlagRoulette) && bounce + 1 >= 3 && !done) {
                         // survive with probability q = clamp(max T, 0.05, 1), drawn from slot 7 of this bounce
-                        float q = clampf(fmaxf(fmaxf(T.x, T.y), T.z), 0.05f, 1.0f);
+                        float q = clampf(fmaxf(fmaxf(Tn.x, Tn.y), Tn.z), 0.05f, 1.0f);
                         if (!(rand01(key, (uint32_t)bounce, 7u) < q)) done = true;
-                        else T = T * __fdiv_rn(1.0f, q);
+                        else Tn = Tn * __fdiv_rn(1.0f, q);
                     }
+                    stT(Tn);
                     ++bounce;
                 }
             }
@@ -133,10 +155,11 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderPar
             lds_acc[slot] = acc.x; lds_acc[kBlock + slot] = acc.y; lds_acc[2 * kBlock + slot] = acc.z;
             ++s;
             ray = camera_ray(rp.cam, px, py); ior = 1.0f;
-            T = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f);
+            stT(mk3(1.f, 1.f, 1.f)); L = mk3(0.f, 0.f, 0.f);
             bounce = 0;
             key = path_key(seed_hash, pixel, s);
         }
+        stL(L);
     }
 
     if (inside) {
@@ -145,9 +168,10 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DRenderPar
     }
     if (COUNT && rp.counters) {
         // wave-level reduction, then one atomic per wave and counter
-        unsigned long long c[4] = { inside ? rp.spp_count : 0u, nrays, tc_total.nodes, tc_total.tris };
+        unsigned long long c[kNumCounters] = { inside ? rp.spp_count : 0u, nrays, tc_total.nodes, tc_total.tris,
+                                               ray_trips, tc_total.node_trips, tc_total.tri_trips, shade_lanes, shade_trips };
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kNumCounters; ++k) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_xor(c[k], off, 64);
             if (lane == 0) atomicAdd(&rp.counters[k], c[k]);
@@ -238,20 +262,32 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const uint32_t geomF4 = sc.num_nodes * 4u + sc.num_tris * 3u;
     const bool fits = geomF4 <= (uint32_t)kLdsGeomF4;
     const size_t geomBytes = fits ? (size_t)geomF4 * 16 : 0;
-    auto lds = [&](int stack) { return ((size_t)stack * sizeof(StackEntry) + 12) * kBlock + geomBytes; };
+    DRenderParams p = rp;
+    p.stack_depth = sc.max_stack < 1 ? 1 : (sc.max_stack > kStackDepth ? kStackDepth : sc.max_stack);
+    const size_t lds = ((size_t)p.stack_depth * sizeof(StackEntry) + 4 * kLaneFloats) * kBlock + geomBytes;
     const bool count = rp.counters != nullptr;
+    static const bool debug = getenv("PTAMD_DEBUG") != nullptr;
     const bool ext = (rp.flags & kFlagRoulette) != 0 || sc.sky_size > 0;
-#define PT_LAUNCH(STACK, LDSG)                                                                                        \
+#define PT_LAUNCH(LDSG, COUNT, EXT)                                                                                   \
     do {                                                                                                              \
-        if (count && ext) hipLaunchKernelGGL((render_kernel<STACK, LDSG, true, true>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);  \
-        else if (count) hipLaunchKernelGGL((render_kernel<STACK, LDSG, true, false>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);   \
-        else if (ext) hipLaunchKernelGGL((render_kernel<STACK, LDSG, false, true>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);     \
-        else hipLaunchKernelGGL((render_kernel<STACK, LDSG, false, false>), dim3(blocks), dim3(kBlock), lds(STACK), stream, sc, rp);             \
+        if (debug) {                                                                                                  \
+            int nb = 0;                                                                                               \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<LDSG, COUNT, EXT>, kBlock, lds);    \
+            fprintf(stderr, "ptamd: render_kernel<%d,%d,%d> stack %d, lds %zu B/block, %d blocks/CU resident\n", (int)LDSG, (int)COUNT, (int)EXT, p.stack_depth, lds, nb); \
+        }                                                                                                             \
+        hipLaunchKernelGGL((render_kernel<LDSG, COUNT, EXT>), dim3(blocks), dim3(kBlock), lds, stream, sc, p);        \
     } while (0)
-    if (fits && sc.max_stack <= 8) PT_LAUNCH(8, true);
-    else if (fits && sc.max_stack <= 16) PT_LAUNCH(16, true);
-    else if (sc.max_stack <= 16) PT_LAUNCH(16, false);
-    else PT_LAUNCH(kStackDepth, false);
+    const int variant = (fits ? 4 : 0) | (count ? 2 : 0) | (ext ? 1 : 0);
+    switch (variant) {
+    case 0: PT_LAUNCH(false, false, false); break;
+    case 1: PT_LAUNCH(false, false, true); break;
+    case 2: PT_LAUNCH(false, true, false); break;
+    case 3: PT_LAUNCH(false, true, true); break;
+    case 4: PT_LAUNCH(true, false, false); break;
+    case 5: PT_LAUNCH(true, false, true); break;
+    case 6: PT_LAUNCH(true, true, false); break;
+    default: PT_LAUNCH(true, true, true); break;
+    }
 #undef PT_LAUNCH
     return hipGetLastError();
 }

@@ -111,12 +111,13 @@ struct DRenderParams {
     DCamera cam;
     float* accum;          // w*h*3
     uint32_t* samples;     // w*h
-    unsigned long long* counters; // [0] samples, [1] rays, [2] BVH node visits, [3] triangle tests, or null
+    unsigned long long* counters; // the 9 fields of ptamd_stats in order, or null
     int32_t x0, y0, x1, y1;
     uint32_t spp_begin, spp_count;
     int32_t depth, albedo_only;
     uint32_t seed, flags;  // flags: PTAMD_FLAG_* of the public header
     int32_t tiles_x, tiles_y; // 8x8-pixel tiles covering the rect
+    int32_t stack_depth, pad; // rows of the per-lane traversal stack in LDS (set by the launcher)
 };
 
 } // namespace ptamd

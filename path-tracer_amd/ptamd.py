@@ -58,7 +58,8 @@ class CRect(C.Structure):
 
 
 class CStats(C.Structure):
-    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64)]
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "nodes", "tris", "ray_trips", "node_trips", "tri_trips",
+                                          "shade_lanes", "shade_trips")]
 
 
 FLAG_COUNT = 1
@@ -528,7 +529,7 @@ def RayTraceParallel(winSize, camera, pathTracer, film, depth, albedoOnly, frame
 def RenderStats():
     s = CStats()
     check(lib().ptamd_render_stats(C.byref(s)))
-    return {"samples": int(s.samples), "rays": int(s.rays), "nodes": int(s.nodes), "tris": int(s.tris)}
+    return {n: int(getattr(s, n)) for n, _ in CStats._fields_}
 
 
 def build_scene(scene, mesh_data=None):

@@ -52,6 +52,12 @@ def main():
         torch.cuda.synchronize()
         st = ptamd.RenderStats()
         rps = st["rays"] / st["samples"]
+        fill = lambda a, b: st[a] / max(1, 64 * st[b])
+        if st["ray_trips"]:
+            print("   per ray: %.1f nodes %.1f tris %.2f shades | wave trips per ray-trip: %.1f node %.1f tri %.2f shade | lanes filled: bounce loop %.0f%% node loop %.0f%% tri loop %.0f%% shading %.0f%%" % (
+                st["nodes"] / st["rays"], st["tris"] / st["rays"], st["shade_lanes"] / st["rays"],
+                st["node_trips"] / st["ray_trips"], st["tri_trips"] / st["ray_trips"], st["shade_trips"] / st["ray_trips"],
+                100 * fill("rays", "ray_trips"), 100 * fill("nodes", "node_trips"), 100 * fill("tris", "tri_trips"), 100 * fill("shade_lanes", "shade_trips")))
         ms = []
         for _ in range(args.reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
