@@ -91,6 +91,7 @@ typedef struct ptamd_stats {
      * tris / tri_trips, shade_lanes / shade_trips is how full the wave was in that loop. */
     uint64_t ray_trips, node_trips, tri_trips;
     uint64_t shade_lanes, shade_trips; /* hits shaded, and wave-level passes through the shading block */
+    uint64_t steal_rounds;             /* wave-level rounds in which idle lanes took over pending subtrees of busy lanes */
 } ptamd_stats;
 
 typedef struct ptamd_scene ptamd_scene;

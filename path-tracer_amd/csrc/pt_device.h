@@ -199,7 +199,7 @@ struct Geom { const float4* nodes; const float4* tris; uint32_t node_stride, nod
 // entry distances to drop such entries on pop was measured slower (8-byte stack traffic, more LDS per block).
 // nodes / tris: per-lane work. node_trips / tri_trips: loop trips the whole wave paid for (counted by the first
 // active lane of each trip), so lanes-per-trip = nodes / node_trips is the lane utilisation of that loop.
-struct TraversalCounts { uint32_t nodes, tris, node_trips, tri_trips; };
+struct TraversalCounts { uint32_t nodes, tris, node_trips, tri_trips, steal_rounds; };
 PT_DEV bool wave_leader() { return (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1; }
 typedef uint32_t StackEntry;
 
@@ -263,11 +263,154 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
     }
 }
 
-// Closest-hit loop of PathTracer::TraceRay (PathTracer.cpp:38-57) over the flat object list.
-template <int BLOCK, bool COUNT = false>
-PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, StackEntry* __restrict__ stack, int slot, TraversalCounts* counts = nullptr)
+// ---------------------------------------------------------------- cooperative traversal (meshes read from global memory)
+//
+// Work sharing inside the wave. A wave pays for the longest traversal among its 64 rays, and with incoherent
+// rays most lanes finish early (measured: 37 % of lanes busy in the node loop on a one-mesh scene, 8 % when a
+// few rays of the wave enter a large mesh). Lanes that run out of work therefore take over pending subtrees of
+// busy lanes: a lane traverses a *task* = (ray, subtree), not necessarily its own ray. The pieces:
+//   * res[lane]: one 64-bit word per ray in LDS, (bits of closest t) << 32 | (triangle + 1). Every accepted hit
+//     is published with an atomic minimum, so the closest hit of a ray is the minimum over all tasks that worked
+//     on it, ties go to the lower triangle index whatever the visiting order, and the word doubles as the
+//     shared pruning bound that every task re-reads when it pops its stack.
+//   * the per-lane stack is used as a deque: its owner pops at the top, a thief takes the oldest entry (the
+//     largest pending subtree) at the bottom.
+//   * a steal round runs when at least kStealMin lanes are idle and some lane has pending entries: idle lane
+//     number r pairs with pending lane number r through a small mailbox, copies that lane's ray with cross-lane
+//     reads and starts on the stolen subtree.
+// Every loop trip some lane advances (node step, leaf, or a steal that hands out a pending subtree), and the
+// loop ends when no lane holds a node, which also means all stacks are empty: stealing happens before a lane
+// with entries can go idle.
+struct Coop { unsigned long long* res; uint32_t* mail; }; // LDS, one entry per thread of the block each
+#ifndef PT_STEAL_MIN
+#define PT_STEAL_MIN 8   // idle lanes that make a steal round worth its cost
+#endif
+#ifndef PT_STEAL_COOL
+#define PT_STEAL_COOL 0  // node trips to wait after a steal round
+#endif
+
+PT_DEV int rank_in(unsigned long long mask) // set bits of mask below this lane
 {
-    TraversalCounts cnt; cnt.nodes = 0; cnt.tris = 0; cnt.node_trips = 0; cnt.tri_trips = 0;
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// `valid`: this lane has a ray of its own to trace through the mesh (every lane of the wave must make the call:
+// lanes without a ray still help). Returns the closest triangle (or -1) and its distance in closestT.
+template <int BLOCK, bool COUNT>
+PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& me, bool valid, f3 o, f3 d, float tMinObj, float& closestT,
+                         StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts& cnt)
+{
+    const float4* __restrict__ nodes = geom.nodes + (size_t)me.node_base * geom.node_step;
+    const float4* __restrict__ tris = geom.tris + (size_t)me.tri_base * geom.tri_step;
+    const uint32_t ns = geom.node_stride, nstep = geom.node_step, ts = geom.tri_stride, tstep = geom.tri_step;
+    const float BIG = 1e30f;
+    const int lane = slot & 63, waveBase = slot & ~63;
+    auto inverse = [&](f3 dir) { return mk3(fabsf(dir.x) > 1e-30f ? frcp(dir.x) : BIG, fabsf(dir.y) > 1e-30f ? frcp(dir.y) : BIG, fabsf(dir.z) > 1e-30f ? frcp(dir.z) : BIG); };
+    f3 inv = inverse(d);
+    f3 oi = o * inv;
+    constexpr int kDone = 0x7fffffff; // never a valid node index
+    coop.res[slot] = ((unsigned long long)__float_as_uint(closestT) << 32); // triangle field 0 = none: an equal t does not replace it
+    int owner = lane;        // whose ray this lane is working on
+    float bound = closestT;  // pruning distance of the current task
+    int sp = 0, bot = 0;     // own stack entries are rows [bot, sp)
+    int cur = valid ? me.root : kDone;
+    int cool = 0;
+    auto pop = [&]() {
+        if (sp > bot) {
+            --sp; cur = (int)stack[sp * BLOCK + slot];
+            // hits that other tasks of this ray have published (high half of the 64-bit word)
+            bound = fminf(bound, __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(&coop.res[waveBase + owner]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+        } else cur = kDone;
+    };
+    // One loop trip is either a node step for every lane that holds an inner node or a leaf pass for every lane
+    // that holds a leaf, whichever group is larger: the branch is wave-uniform, so the two bodies are never issued
+    // for a partial wave in the same trip (the point of "while-while"), and leaf holders do not wait for the
+    // slowest descent.
+    for (;;) {
+        const bool isInner = (uint32_t)cur < (uint32_t)kDone, isLeaf = cur < 0;
+        const int nInner = __popcll(__ballot(isInner)), nLeaf = __popcll(__ballot(isLeaf));
+        if (nInner + nLeaf == 0) break;
+        if (nInner >= nLeaf) {
+            if (isInner) {
+                if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
+                const float4* n = nodes + (size_t)cur * nstep;
+                float4 a = n[0], b = n[ns], c = n[2 * ns], r = n[3 * ns];
+                float lx0 = fmaf(a.x, inv.x, -oi.x), lx1 = fmaf(a.w, inv.x, -oi.x);
+                float ly0 = fmaf(a.y, inv.y, -oi.y), ly1 = fmaf(b.x, inv.y, -oi.y);
+                float lz0 = fmaf(a.z, inv.z, -oi.z), lz1 = fmaf(b.y, inv.z, -oi.z);
+                float rx0 = fmaf(b.z, inv.x, -oi.x), rx1 = fmaf(c.y, inv.x, -oi.x);
+                float ry0 = fmaf(b.w, inv.y, -oi.y), ry1 = fmaf(c.z, inv.y, -oi.y);
+                float rz0 = fmaf(c.x, inv.z, -oi.z), rz1 = fmaf(c.w, inv.z, -oi.z);
+                float lmin = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), 0.0f));
+                float lmax = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), bound));
+                float rmin = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), 0.0f));
+                float rmax = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), bound));
+                bool hl = lmax >= lmin, hr = rmax >= rmin;
+                int left = __float_as_int(r.x), right = __float_as_int(r.y);
+                if (hl && hr) {
+                    bool leftNear = lmin < rmin; // Mesh.cpp:143
+                    stack[sp * BLOCK + slot] = (uint32_t)(leftNear ? right : left);
+                    ++sp;
+                    cur = leftNear ? left : right;
+                } else if (hl || hr) {
+                    cur = hl ? left : right;
+                } else {
+                    pop();
+                }
+            }
+            // ---- steal round
+            const bool idle = cur == kDone, rich = sp > bot;
+            const unsigned long long idleMask = __ballot(idle), richMask = __ballot(rich);
+            --cool;
+            if (cool < 0 && richMask != 0ull && __popcll(idleMask) >= PT_STEAL_MIN) {
+                cool = PT_STEAL_COOL;
+                if (COUNT) { if (wave_leader()) ++cnt.steal_rounds; }
+                const int pairs = min(__popcll(idleMask), __popcll(richMask));
+                const int r = rank_in(idle ? idleMask : richMask);
+                const bool victim = rich && r < pairs, thief = idle && r < pairs;
+                if (victim) coop.mail[waveBase + r] = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier(); // LDS executes a wave's operations in order; this keeps the compiler from reordering them
+                int src = lane;
+                if (thief) src = (int)coop.mail[waveBase + r];
+                // every lane takes part in the cross-lane reads; a lane that is not a thief reads itself
+                o.x = __shfl(o.x, src, 64); o.y = __shfl(o.y, src, 64); o.z = __shfl(o.z, src, 64);
+                d.x = __shfl(d.x, src, 64); d.y = __shfl(d.y, src, 64); d.z = __shfl(d.z, src, 64);
+                tMinObj = __shfl(tMinObj, src, 64); bound = __shfl(bound, src, 64); owner = __shfl(owner, src, 64);
+                const int sBot = __shfl(bot, src, 64);
+                if (thief) {
+                    inv = inverse(d); oi = o * inv;
+                    cur = (int)stack[sBot * BLOCK + waveBase + src];
+                    sp = 0; bot = 0;
+                }
+                if (victim) ++bot;
+            }
+        } else if (isLeaf) {
+            uint32_t code = ~(uint32_t)cur;
+            uint32_t first = code >> 3, cnt_tris = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < cnt_tris; ++i) {
+                if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
+                float t, u, v; int group;
+                if (!tri_test(tris + (size_t)(first + i) * tstep, ts, o, d, t, u, v, group)) continue;
+                if (t < tMinObj || t > bound) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
+                if ((me.flags & 1u) && group >= 0 && !alpha_pass(sc, me, (int)(first + i), group, u, v)) continue; // Mesh.cpp:106-125
+                bound = t;
+                atomicMin(&coop.res[waveBase + owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(first + i + 1u));
+            }
+            pop();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long best = __hip_atomic_load(&coop.res[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    closestT = __uint_as_float((uint32_t)(best >> 32));
+    return (int)(uint32_t)best - 1;
+}
+
+// Closest-hit loop of PathTracer::TraceRay (PathTracer.cpp:38-57) over the flat object list. COOP selects the
+// work-sharing traversal (every lane of the wave must then make the call together).
+template <int BLOCK, bool COUNT, bool COOP>
+PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts* counts = nullptr)
+{
+    TraversalCounts cnt; cnt.nodes = 0; cnt.tris = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.steal_rounds = 0;
     const float kTMin = 1e-4f, kTMax = 1e30f;
     Best best; best.t = kTMax; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
     for (int i = 0; i < sc.num_objects; ++i) {
@@ -283,14 +426,24 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
             f3 oo = xform_point(me.minv, ray.o);
             f3 dd = xform_dir(me.minv, ray.d);
             float len2 = dot(dd, dd);
-            if (len2 == 0.0f) continue;           // Mesh.cpp:64
+            const bool valid = len2 != 0.0f;       // Mesh.cpp:64
+            if (!COOP && !valid) continue;
             float dirLen = fsqrt(len2);
             float invLen = frcp(dirLen);
             dd = dd * invLen;
             float tMinObj = kTMin * dirLen;
             float closestT = best.t * dirLen;      // Mesh.cpp:72-75
             int tri = -1; float u = 0.f, v = 0.f;
-            mesh_traverse<BLOCK, COUNT>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt);
+            if (COOP) {
+                tri = mesh_traverse_coop<BLOCK, COUNT>(sc, geom, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt);
+                if (!valid) tri = -1;
+                if (tri >= 0) { // barycentrics of the winner: its test repeated on this lane's own ray
+                    float tt; int gg;
+                    (void)tri_test(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, 1u, oo, dd, tt, u, v, gg);
+                }
+            } else {
+                mesh_traverse<BLOCK, COUNT>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt);
+            }
             if (tri >= 0) {
                 float tW = closestT * invLen;      // Mesh.cpp:249
                 if (tW < best.t) { best.t = tW; best.obj = i; best.tri = tri; best.u = u; best.v = v; }

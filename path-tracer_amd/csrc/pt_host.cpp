@@ -33,7 +33,7 @@ thread_local std::string g_error;
 hipStream_t g_own_stream = nullptr;
 hipStream_t g_stream = nullptr;
 bool g_initialised = false;
-constexpr int kNumCounters = 9;
+constexpr int kNumCounters = 10;
 unsigned long long* g_counters = nullptr; // device, kNumCounters x u64 (the fields of ptamd_stats)
 
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
@@ -692,7 +692,7 @@ int ptamd_render_stats(ptamd_stats* out)
     PT_HIP(hipMemcpyAsync(c, g_counters, sizeof c, hipMemcpyDeviceToHost, g_stream));
     PT_HIP(hipStreamSynchronize(g_stream));
     out->samples = c[0]; out->rays = c[1]; out->nodes = c[2]; out->tris = c[3];
-    out->ray_trips = c[4]; out->node_trips = c[5]; out->tri_trips = c[6]; out->shade_lanes = c[7]; out->shade_trips = c[8];
+    out->ray_trips = c[4]; out->node_trips = c[5]; out->tri_trips = c[6]; out->shade_lanes = c[7]; out->shade_trips = c[8]; out->steal_rounds = c[9];
     return PTAMD_OK;
 }
 

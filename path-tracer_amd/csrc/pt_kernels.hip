@@ -43,7 +43,7 @@ PT_DEV void add_sample(f3& acc, f3 c)
     acc = acc + c;
 }
 
-// Dynamic LDS layout: [rp.stack_depth][kBlock] traversal stack entries (the depth of the scene's deepest tree), [kLaneFloats][kBlock] parked per-lane floats, then
+// Dynamic LDS layout: [rp.stack_depth][kBlock] traversal stack entries (the depth of the scene's deepest tree), [kLaneFloats][kBlock] parked per-lane floats,
 // (LDS_GEOM) the staged nodes and triangles.
 // Occupancy: the bounce loop is latency bound (dependent VALU chains, LDS and L1 round trips), and its
 // throughput scales almost linearly with resident waves up to 5 per SIMD; asking for 5 holds the register
@@ -52,18 +52,27 @@ PT_DEV void add_sample(f3& acc, f3 c)
 // EXT: the two options the reference does not have, Russian roulette and the cubemap sky; a build of its own so
 // that the default kernel carries neither their registers nor their branches.
 constexpr uint32_t kFlagRoulette = 2u; // PTAMD_FLAG_RUSSIAN_ROULETTE
-constexpr int kNumCounters = 9;         // fields of ptamd_stats, in order
+constexpr int kNumCounters = 10;        // fields of ptamd_stats, in order
 #ifndef PT_WAVES
 #define PT_WAVES 5
 #endif
+#ifndef PT_WAVES_COOP
+#define PT_WAVES_COOP 4 // the cooperative traversal needs ~118 VGPRs; spilling them costs more than the fifth wave brings
+#endif
 constexpr int kLaneFloats = 3;          // per-lane floats parked in LDS: the film sum of the lane's pixel
 template <bool LDS_GEOM, bool COUNT, bool EXT>
-__global__ __launch_bounds__(kBlock, PT_WAVES) void render_kernel(DScene sc, DRenderParams rp)
+__global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void render_kernel(DScene sc, DRenderParams rp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     StackEntry* stack = reinterpret_cast<StackEntry*>(lds_raw);
     const uint32_t stackBytes = (uint32_t)rp.stack_depth * kBlock * (uint32_t)sizeof(StackEntry);
     float* lds_acc = reinterpret_cast<float*>(lds_raw + stackBytes); // [kLaneFloats][kBlock]
+    // Either the staged geometry (small scenes, lean traversal) or the work-sharing words of the cooperative
+    // traversal (8 + 4 bytes per lane; meshes read from global memory) follow the per-lane floats.
+    constexpr bool COOP = !LDS_GEOM;
+    Coop coop;
+    coop.res = reinterpret_cast<unsigned long long*>(lds_raw + stackBytes + 4 * kLaneFloats * kBlock);
+    coop.mail = reinterpret_cast<uint32_t*>(lds_raw + stackBytes + (4 * kLaneFloats + 8) * kBlock);
     float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + 4 * kLaneFloats * kBlock);
     const Geom geom = stage_geometry<LDS_GEOM>(sc, lds_geom);
     const int slot = threadIdx.x;
@@ -101,19 +110,19 @@ __global__ __launch_bounds__(kBlock, PT_WAVES) void render_kernel(DScene sc, DRe
     int bounce = 0;
     uint32_t key = path_key(seed_hash, pixel, s);
     uint32_t nrays = 0;
-    TraversalCounts tc_total; tc_total.nodes = 0; tc_total.tris = 0; tc_total.node_trips = 0; tc_total.tri_trips = 0;
+    TraversalCounts tc_total; tc_total.nodes = 0; tc_total.tris = 0; tc_total.node_trips = 0; tc_total.tri_trips = 0; tc_total.steal_rounds = 0;
     uint32_t ray_trips = 0, shade_lanes = 0, shade_trips = 0; // wave-level trips of the bounce loop and of its shading block
 
     while (s < s_end) {
         Best best;
         if (COUNT) {
             TraversalCounts tc;
-            best = closest_hit<kBlock, true>(sc, geom, ray, stack, slot, &tc);
+            best = closest_hit<kBlock, true, COOP>(sc, geom, ray, stack, coop, slot, &tc);
             ++nrays; tc_total.nodes += tc.nodes; tc_total.tris += tc.tris;
-            tc_total.node_trips += tc.node_trips; tc_total.tri_trips += tc.tri_trips;
+            tc_total.node_trips += tc.node_trips; tc_total.tri_trips += tc.tri_trips; tc_total.steal_rounds += tc.steal_rounds;
             if (wave_leader()) ++ray_trips;
         } else {
-            best = closest_hit<kBlock, false>(sc, geom, ray, stack, slot);
+            best = closest_hit<kBlock, false, COOP>(sc, geom, ray, stack, coop, slot);
         }
         bool done;
         f3 L = ldL();
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES) void render_kernel(DScene sc, DRe
     if (COUNT && rp.counters) {
         // wave-level reduction, then one atomic per wave and counter
         unsigned long long c[kNumCounters] = { inside ? rp.spp_count : 0u, nrays, tc_total.nodes, tc_total.tris,
-                                               ray_trips, tc_total.node_trips, tc_total.tri_trips, shade_lanes, shade_trips };
+                                               ray_trips, tc_total.node_trips, tc_total.tri_trips, shade_lanes, shade_trips, tc_total.steal_rounds };
 #pragma unroll
         for (int k = 0; k < kNumCounters; ++k) {
 #pragma unroll
@@ -194,6 +203,9 @@ template <int STACK>
 __global__ __launch_bounds__(kBlock) void closest_hits_kernel(DScene sc, const float* rays, uint32_t n, float* rec, uint32_t* counts)
 {
     __shared__ StackEntry stack[STACK * kBlock];
+    __shared__ unsigned long long coop_res[kBlock];
+    __shared__ uint32_t coop_mail[kBlock];
+    Coop coop; coop.res = coop_res; coop.mail = coop_mail;
     Geom geom; geom.nodes = sc.nodes; geom.tris = sc.tris;
     geom.node_stride = 1; geom.node_step = 4; geom.tri_stride = 1; geom.tri_step = 3;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void closest_hits_kernel(DScene sc, const f
     ray.o = mk3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
     ray.d = mk3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     TraversalCounts tc;
-    Best best = closest_hit<kBlock, true>(sc, geom, ray, stack, (int)threadIdx.x, &tc);
+    Best best = closest_hit<kBlock, true, true>(sc, geom, ray, stack, coop, (int)threadIdx.x, &tc);
     if (counts) { counts[2 * (size_t)i] = tc.nodes; counts[2 * (size_t)i + 1] = tc.tris; }
     float* o = rec + (size_t)i * 20;
     for (int k = 0; k < 20; ++k) o[k] = 0.f;
@@ -264,7 +276,7 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const size_t geomBytes = fits ? (size_t)geomF4 * 16 : 0;
     DRenderParams p = rp;
     p.stack_depth = sc.max_stack < 1 ? 1 : (sc.max_stack > kStackDepth ? kStackDepth : sc.max_stack);
-    const size_t lds = ((size_t)p.stack_depth * sizeof(StackEntry) + 4 * kLaneFloats) * kBlock + geomBytes;
+    const size_t lds = ((size_t)p.stack_depth * sizeof(StackEntry) + 4 * kLaneFloats + (fits ? 0 : 12)) * kBlock + geomBytes;
     const bool count = rp.counters != nullptr;
     static const bool debug = getenv("PTAMD_DEBUG") != nullptr;
     const bool ext = (rp.flags & kFlagRoulette) != 0 || sc.sky_size > 0;

@@ -111,7 +111,7 @@ struct DRenderParams {
     DCamera cam;
     float* accum;          // w*h*3
     uint32_t* samples;     // w*h
-    unsigned long long* counters; // the 9 fields of ptamd_stats in order, or null
+    unsigned long long* counters; // the 10 fields of ptamd_stats in order, or null
     int32_t x0, y0, x1, y1;
     uint32_t spp_begin, spp_count;
     int32_t depth, albedo_only;

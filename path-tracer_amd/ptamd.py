@@ -59,7 +59,7 @@ class CRect(C.Structure):
 
 class CStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "nodes", "tris", "ray_trips", "node_trips", "tri_trips",
-                                          "shade_lanes", "shade_trips")]
+                                          "shade_lanes", "shade_trips", "steal_rounds")]
 
 
 FLAG_COUNT = 1

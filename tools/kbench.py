@@ -31,6 +31,19 @@ def main():
         "glass_mirror": (presets.glass_mirror(1920, 1080), 32),
         "blob_mixed": (presets.mixed("tests/golden/blob.glb", 1920, 1080, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0)), 8),
     }
+    if "bumpy_1m" in args.scenes.split(","):
+        from scenes import gltf_io
+        prim = gltf_io.bumpy_sphere_primitive(500, 1000, radius=1.0, bump=0.06, freq=9)
+        idx = prim["indices"].reshape(-1, 3)
+        data = {"positions": np.ascontiguousarray(prim["positions"][idx].reshape(-1, 9)),
+                "normals": np.ascontiguousarray(prim["normals"][idx].reshape(-1, 9)),
+                "uvs": np.ascontiguousarray(prim["uvs"][idx].reshape(-1, 6)),
+                "group": np.zeros(len(idx), np.int32),
+                "groups": [dict(gltf_io.default_pbr(), base_color_factor=[0.7, 0.6, 0.5, 1.0], metallic_factor=0.0, roughness_factor=0.6, name="m")],
+                "images": []}
+        objs = presets.cornell_room_boxes()
+        objs.append({"type": "mesh", "data": data, "pos": (2.775, 2.2, 2.2), "rot": (20.0, 30.0, 0.0), "scale": (2.3, 2.0, 2.1)})
+        table["bumpy_1m"] = ({"film": (1920, 1080), "camera": presets.default_camera(), "background": (0.2, 0.2, 0.2), "objects": objs}, 8)
     for name in args.scenes.split(","):
         scene, depth = table[name]
         w, h = scene["film"]
@@ -54,10 +67,10 @@ def main():
         rps = st["rays"] / st["samples"]
         fill = lambda a, b: st[a] / max(1, 64 * st[b])
         if st["ray_trips"]:
-            print("   per ray: %.1f nodes %.1f tris %.2f shades | wave trips per ray-trip: %.1f node %.1f tri %.2f shade | lanes filled: bounce loop %.0f%% node loop %.0f%% tri loop %.0f%% shading %.0f%%" % (
+            print("   per ray: %.1f nodes %.1f tris %.2f shades | wave trips per ray-trip: %.1f node %.1f tri %.2f shade | lanes filled: bounce loop %.0f%% node loop %.0f%% tri loop %.0f%% shading %.0f%% | %.1f steal rounds per ray-trip" % (
                 st["nodes"] / st["rays"], st["tris"] / st["rays"], st["shade_lanes"] / st["rays"],
                 st["node_trips"] / st["ray_trips"], st["tri_trips"] / st["ray_trips"], st["shade_trips"] / st["ray_trips"],
-                100 * fill("rays", "ray_trips"), 100 * fill("nodes", "node_trips"), 100 * fill("tris", "tri_trips"), 100 * fill("shade_lanes", "shade_trips")))
+                100 * fill("rays", "ray_trips"), 100 * fill("nodes", "node_trips"), 100 * fill("tris", "tri_trips"), 100 * fill("shade_lanes", "shade_trips"), st["steal_rounds"] / st["ray_trips"]))
         ms = []
         for _ in range(args.reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
