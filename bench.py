@@ -39,7 +39,7 @@ def algorithmic_flops(cnt):
 
 def cpu_baseline(scene, depth, budget_s=15.0):
     """Times the CPU oracle (the validated restatement of the reference) on a bounded sample: the same
-    scene and camera at 1/8 resolution per axis, spp chosen so the run takes about budget_s."""
+    scene and camera at 1/4 resolution per axis, spp chosen so the run takes about budget_s."""
     from oracle import pyoracle as po
     cores = min(len(os.sched_getaffinity(0)), 16)
     w, h = W // 4, H // 4
@@ -54,6 +54,20 @@ def cpu_baseline(scene, depth, budget_s=15.0):
     nsamples = w * h * spp
     return {"value": nsamples / dt * 1e-6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": "%dx%d, %d spp, depth %d (same scene and camera, 1/16 of the pixels), %.1f s of CPU wall time" % (w, h, spp, depth, dt)}, cnt
+
+
+def measured_traffic(spp, depth):
+    """HBM bytes per launch of the render kernel from the memory-side counters (rocprofv3 FETCH_SIZE / WRITE_SIZE,
+    collected in separate passes by tools/profile_bench.sh and committed under profiles/). Only valid for the
+    configuration it was measured on; None otherwise."""
+    import glob
+    if (spp, depth) != (1024, 8):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return float(json.load(f)["bytes_per_launch"])
 
 
 def main():
@@ -145,12 +159,13 @@ def main():
             executed_per_sample = (54.0 * stats["nodes"] + 47.0 * stats["tris"] + 250.0 * stats["rays"]) / max(1, stats["samples"])
             executed = executed_per_sample * float(W) * H * args.spp / (kernel_ms * 1e-3) * 1e-12
             out["roofline"] = {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                               "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": measured_traffic(args.spp, args.depth),
+                               "traffic_unit": "bytes per launch (film read + write; PMC pass committed under profiles/)",
                                "kernel": "render_kernel", "flops_per_sample": flops_per_sample,
                                "executed_flops_per_sample": executed_per_sample, "executed": executed,
                                "executed_frac": executed / FP32_VECTOR_PEAK_TFLOPS,
                                "note": "fp32 vector ALU bound (no MFMA: not a dense contraction); scene (14 KB) and film "
-                                       "(16 B/pixel/launch) traffic is negligible; `achieved` prices the reference "
+                                       "(32 B/pixel/launch) traffic is negligible; `achieved` prices the reference "
                                        "algorithm's counted slab/triangle/box tests and shades on this scene (CPU oracle "
                                        "counters), `executed` the tests this kernel's own BVH walk performed"}
             out["cpu_baseline"] = base
