@@ -159,6 +159,14 @@ int ptamd_scene_commit(ptamd_scene* s);
 
 /* ---- model ingest: ModelLoader::LoadGLTF (ModelLoader.h:171-420) ---------------------------- */
 int ptamd_model_load(const char* path, ptamd_model** out);
+/* The same with options that go beyond the reference (flags = 0 is ptamd_model_load):
+ * PTAMD_LOAD_NODE_TRANSFORMS applies the glTF scene graph to the vertices (the reference ignores nodes,
+ * ModelLoader.h:204-206): each node of the default scene that refers to a mesh emits it under the product of the
+ * node matrices from its root. PTAMD_LOAD_OBJ also accepts Wavefront .obj (+ .mtl) files, which the reference
+ * rejects (ModelLoader.h:139-142). */
+#define PTAMD_LOAD_NODE_TRANSFORMS 1u
+#define PTAMD_LOAD_OBJ 2u
+int ptamd_model_load_ex(const char* path, uint32_t flags, ptamd_model** out);
 int ptamd_model_desc(const ptamd_model* m, ptamd_mesh_desc* out); /* pointers stay valid until ptamd_model_free */
 const char* ptamd_model_group_name(const ptamd_model* m, uint32_t group);
 void ptamd_model_free(ptamd_model* m);

@@ -1,5 +1,9 @@
 #include "gltf_loader.h"
 
+#include <fstream>
+#include <functional>
+#include <sstream>
+
 #include <zlib.h>
 
 #include <cmath>
@@ -278,12 +282,13 @@ int texture_source(const Doc& d, const JValue* texInfo)
 
 } // namespace
 
-void load_gltf(const std::string& path, Model& out)
+void load_gltf(const std::string& path, Model& out, uint32_t flags)
 {
     // ModelLoader.h:129-142
     std::string ext;
     size_t dot = path.find_last_of('.');
     if (dot != std::string::npos) ext = path.substr(dot + 1);
+    if ((flags & kLoadObj) && (ext == "obj" || ext == "OBJ")) { load_obj(path, out); return; }
     if (ext != "glb" && ext != "gltf") throw std::runtime_error("Model only supports .glb/.gltf: " + path);
 
     Doc d;
@@ -347,9 +352,24 @@ void load_gltf(const std::string& path, Model& out)
     const JValue* mats = d.root->get("materials");
     const JValue* meshes = d.root->get("meshes");
     if (!meshes) return;
-    for (const auto& mesh : meshes->arr) {
+    // M: node-to-world matrix (row-major 3x4) applied to the vertices, or null for the reference's behaviour of
+    // ignoring the scene graph (ModelLoader.h:204-206).
+    auto emit_mesh = [&](const JValue& meshRef, const double* M) {
+        const JValue* mesh = &meshRef;
+        double N[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }; // inverse transpose of the upper 3x3, for normals
+        if (M) {
+            const double a = M[0], b = M[1], c = M[2], d2 = M[4], e = M[5], f = M[6], g = M[8], h = M[9], i = M[10];
+            const double det = a * (e * i - f * h) - b * (d2 * i - f * g) + c * (d2 * h - e * g);
+            if (std::fabs(det) > 1e-300) {
+                const double id = 1.0 / det;
+                // cofactor matrix / det = inverse transpose
+                N[0] = (e * i - f * h) * id; N[1] = (f * g - d2 * i) * id; N[2] = (d2 * h - e * g) * id;
+                N[3] = (c * h - b * i) * id; N[4] = (a * i - c * g) * id; N[5] = (b * g - a * h) * id;
+                N[6] = (b * f - c * e) * id; N[7] = (c * d2 - a * f) * id; N[8] = (a * e - b * d2) * id;
+            }
+        }
         const JValue* prims = mesh->get("primitives");
-        if (!prims) continue;
+        if (!prims) return;
         for (const auto& prim : prims->arr) {
             const JValue* mode = prim->get("mode");
             if (mode && (int)mode->num != 4) throw std::runtime_error("Only TRIANGLES are supported");
@@ -430,9 +450,18 @@ void load_gltf(const std::string& path, Model& out)
                     uint32_t vi = fetch_index(f + (size_t)k);
                     if (vi >= pos.count) throw std::runtime_error("glTF: vertex index out of range");
                     float p[3]; std::memcpy(p, pos.ptr + (size_t)vi * pos.stride, 12);
-                    out.positions.insert(out.positions.end(), p, p + 3);
                     float n[3] = { 0.f, 0.f, 0.f };
                     if (hasN && vi < nrm.count) std::memcpy(n, nrm.ptr + (size_t)vi * nrm.stride, 12);
+                    if (M) {
+                        const double x = p[0], y = p[1], z = p[2];
+                        for (int r = 0; r < 3; ++r) p[r] = (float)(M[4 * r] * x + M[4 * r + 1] * y + M[4 * r + 2] * z + M[4 * r + 3]);
+                        const double nx = n[0], ny = n[1], nz = n[2];
+                        double t[3];
+                        for (int r = 0; r < 3; ++r) t[r] = N[3 * r] * nx + N[3 * r + 1] * ny + N[3 * r + 2] * nz;
+                        const double len = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+                        for (int r = 0; r < 3; ++r) n[r] = len > 0.0 ? (float)(t[r] / len) : 0.f;
+                    }
+                    out.positions.insert(out.positions.end(), p, p + 3);
                     out.normals.insert(out.normals.end(), n, n + 3);
                     float t[2] = { 0.f, 0.f };
                     if (hasT && vi < uv.count) std::memcpy(t, uv.ptr + (size_t)vi * uv.stride, 8);
@@ -441,7 +470,181 @@ void load_gltf(const std::string& path, Model& out)
                 out.group.push_back(groupIndex);
             }
         }
+    };
+
+    if (!(flags & kLoadNodeTransforms)) {
+        for (const auto& mesh : meshes->arr) emit_mesh(*mesh, nullptr);
+        return;
     }
+    // Scene-graph mode (not in the reference): every node of the default scene that refers to a mesh emits that mesh
+    // under the product of the local matrices from its root (glTF 2.0: `matrix`, or T * R * S).
+    const JValue* nodes = d.root->get("nodes");
+    if (!nodes) return;
+    auto local = [&](const JValue& n, double L[12]) {
+        const double I[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+        std::memcpy(L, I, sizeof I);
+        if (const JValue* m = n.get("matrix")) {
+            if (m->arr.size() == 16) for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) L[4 * r + c] = m->arr[(size_t)(4 * c + r)]->num; // column-major
+            return;
+        }
+        double t[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 1 }, sc[3] = { 1, 1, 1 };
+        if (const JValue* v = n.get("translation")) if (v->arr.size() == 3) for (int k = 0; k < 3; ++k) t[k] = v->arr[(size_t)k]->num;
+        if (const JValue* v = n.get("rotation")) if (v->arr.size() == 4) for (int k = 0; k < 4; ++k) q[k] = v->arr[(size_t)k]->num;
+        if (const JValue* v = n.get("scale")) if (v->arr.size() == 3) for (int k = 0; k < 3; ++k) sc[k] = v->arr[(size_t)k]->num;
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        const double R[9] = { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                              2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                              2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y) };
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) L[4 * r + c] = R[3 * r + c] * sc[c]; L[4 * r + 3] = t[r]; }
+    };
+    std::vector<int> onPath;
+    std::function<void(size_t, const double*)> visit = [&](size_t ni, const double* P) {
+        if (ni >= nodes->arr.size()) throw std::runtime_error("glTF: node index out of range");
+        for (int seen : onPath) if ((size_t)seen == ni) throw std::runtime_error("glTF: cycle in the node hierarchy");
+        onPath.push_back((int)ni);
+        const JValue& n = *nodes->arr[ni];
+        double L[12], W[12];
+        local(n, L);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c)
+                W[4 * r + c] = P[4 * r] * L[c] + P[4 * r + 1] * L[4 + c] + P[4 * r + 2] * L[8 + c] + (c == 3 ? P[4 * r + 3] : 0.0);
+        if (const JValue* m = n.get("mesh")) if (m->is_number() && m->num >= 0) emit_mesh(at(meshes, (size_t)m->num, "meshes"), W);
+        if (const JValue* ch = n.get("children")) for (const auto& c : ch->arr) visit((size_t)c->num, W);
+        onPath.pop_back();
+    };
+    const double I[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+    const JValue* scenes = d.root->get("scenes");
+    if (scenes && !scenes->arr.empty()) {
+        size_t si = (d.root->get("scene") && d.root->get("scene")->is_number()) ? (size_t)d.root->get("scene")->num : 0;
+        const JValue& sc = at(scenes, si, "scenes");
+        if (const JValue* roots = sc.get("nodes")) for (const auto& r : roots->arr) visit((size_t)r->num, I);
+    } else { // no scene: every node that is nobody's child is a root
+        std::vector<char> isChild(nodes->arr.size(), 0);
+        for (const auto& n : nodes->arr) if (const JValue* ch = n->get("children")) for (const auto& c : ch->arr) if ((size_t)c->num < isChild.size()) isChild[(size_t)c->num] = 1;
+        for (size_t i = 0; i < nodes->arr.size(); ++i) if (!isChild[i]) visit(i, I);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ Wavefront OBJ
+// Not in the reference (ModelLoader accepts only glTF, ModelLoader.h:139-142). Reads v / vn / vt / f (polygons as
+// triangle fans, negative indices), groups faces by `usemtl`, and takes base colour, emission, index of refraction,
+// dissolve and the PBR extension keys (Pr, Pm) from the `mtllib` file; `map_Kd` PNG files become base-colour
+// textures. Faces without normals get their geometric normal.
+namespace {
+struct ObjMaterial { std::string name; ptamd_pbr pbr; };
+
+std::vector<ObjMaterial> load_mtl(const std::string& path, Model& out)
+{
+    std::vector<ObjMaterial> mats;
+    std::ifstream f(path);
+    if (!f) return mats;
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream in(line);
+        std::string key;
+        if (!(in >> key) || key[0] == '#') continue;
+        if (key == "newmtl") {
+            ObjMaterial m; in >> m.name; ptamd_pbr_default(&m.pbr);
+            m.pbr.metallic_factor = 0.0f; m.pbr.roughness_factor = 1.0f;
+            mats.push_back(m);
+            continue;
+        }
+        if (mats.empty()) continue;
+        ptamd_pbr& g = mats.back().pbr;
+        if (key == "Kd") in >> g.base_color_factor[0] >> g.base_color_factor[1] >> g.base_color_factor[2];
+        else if (key == "Ke") in >> g.emissive_factor[0] >> g.emissive_factor[1] >> g.emissive_factor[2];
+        else if (key == "Ni") in >> g.ior;
+        else if (key == "d") { float d = 1.0f; in >> d; g.transmission_factor = 1.0f - d; }
+        else if (key == "Tr") in >> g.transmission_factor;
+        else if (key == "Pr") in >> g.roughness_factor;
+        else if (key == "Pm") in >> g.metallic_factor;
+        else if (key == "Ns") { float ns = 0.f; in >> ns; g.roughness_factor = std::sqrt(2.0f / (std::max(ns, 0.0f) + 2.0f)); } // Blinn exponent -> roughness
+        else if (key == "map_Kd") {
+            std::string file; in >> file;
+            std::vector<uint8_t> raw = read_file(dir_of(path) + "/" + file);
+            int w = 0, h = 0; std::vector<uint8_t> rgba;
+            decode_png_rgba(raw.data(), raw.size(), w, h, rgba);
+            out.image_data.push_back(std::move(rgba));
+            ptamd_image pi; pi.width = w; pi.height = h; pi.channels = 4; pi.data = nullptr;
+            out.images.push_back(pi);
+            g.base_color_tex = (int32_t)out.images.size() - 1;
+        }
+    }
+    return mats;
+}
+} // namespace
+
+void load_obj(const std::string& path, Model& out)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("Failed to load OBJ model: " + path);
+    out = Model();
+    std::vector<float> V, VN, VT;
+    std::vector<ObjMaterial> mats;
+    int group = -1;
+    std::string line;
+    auto resolve = [](long i, size_t n) -> long { return i > 0 ? i - 1 : (i < 0 ? (long)n + i : -1); };
+    while (std::getline(f, line)) {
+        std::istringstream in(line);
+        std::string key;
+        if (!(in >> key) || key[0] == '#') continue;
+        if (key == "v") { float x, y, z; in >> x >> y >> z; V.insert(V.end(), { x, y, z }); }
+        else if (key == "vn") { float x, y, z; in >> x >> y >> z; VN.insert(VN.end(), { x, y, z }); }
+        else if (key == "vt") { float u = 0, v = 0; in >> u >> v; VT.insert(VT.end(), { u, v }); }
+        else if (key == "mtllib") { std::string file; in >> file; mats = load_mtl(dir_of(path) + "/" + file, out); }
+        else if (key == "usemtl") {
+            std::string name; in >> name;
+            group = -1;
+            for (size_t g = 0; g < out.group_names.size(); ++g) if (out.group_names[g] == name) group = (int)g;
+            if (group < 0) {
+                ptamd_pbr def; ptamd_pbr_default(&def); def.metallic_factor = 0.0f; def.roughness_factor = 1.0f;
+                for (const ObjMaterial& m : mats) if (m.name == name) def = m.pbr;
+                out.groups.push_back(def); out.group_names.push_back(name);
+                group = (int)out.groups.size() - 1;
+            }
+        } else if (key == "f") {
+            struct Corner { long v, t, n; };
+            std::vector<Corner> cs;
+            std::string tok;
+            while (in >> tok) {
+                Corner c{ 0, 0, 0 };
+                size_t s1 = tok.find('/');
+                c.v = std::atol(tok.substr(0, s1).c_str());
+                if (s1 != std::string::npos) {
+                    size_t s2 = tok.find('/', s1 + 1);
+                    std::string t = tok.substr(s1 + 1, s2 == std::string::npos ? std::string::npos : s2 - s1 - 1);
+                    if (!t.empty()) c.t = std::atol(t.c_str());
+                    if (s2 != std::string::npos) c.n = std::atol(tok.substr(s2 + 1).c_str());
+                }
+                cs.push_back(c);
+            }
+            for (size_t k = 1; k + 1 < cs.size(); ++k) {
+                const Corner tri[3] = { cs[0], cs[k], cs[k + 1] };
+                float P[9], Nn[9] = { 0 }, T[6] = { 0 };
+                bool haveN = true;
+                for (int j = 0; j < 3; ++j) {
+                    long vi = resolve(tri[j].v, V.size() / 3);
+                    if (vi < 0 || (size_t)vi >= V.size() / 3) throw std::runtime_error("OBJ: vertex index out of range");
+                    std::memcpy(P + 3 * j, &V[3 * (size_t)vi], 12);
+                    long ni = resolve(tri[j].n, VN.size() / 3);
+                    if (ni >= 0 && (size_t)ni < VN.size() / 3) std::memcpy(Nn + 3 * j, &VN[3 * (size_t)ni], 12); else haveN = false;
+                    long ti = resolve(tri[j].t, VT.size() / 2);
+                    if (ti >= 0 && (size_t)ti < VT.size() / 2) std::memcpy(T + 2 * j, &VT[2 * (size_t)ti], 8);
+                }
+                if (!haveN) {
+                    float e1[3] = { P[3] - P[0], P[4] - P[1], P[5] - P[2] }, e2[3] = { P[6] - P[0], P[7] - P[1], P[8] - P[2] };
+                    float n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+                    float len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                    for (int j = 0; j < 3; ++j) for (int c = 0; c < 3; ++c) Nn[3 * j + c] = len > 0.f ? n[c] / len : 0.f;
+                }
+                out.positions.insert(out.positions.end(), P, P + 9);
+                out.normals.insert(out.normals.end(), Nn, Nn + 9);
+                out.texcoords.insert(out.texcoords.end(), T, T + 6);
+                out.group.push_back(group);
+            }
+        }
+    }
+    for (size_t i = 0; i < out.images.size(); ++i) out.images[i].data = out.image_data[i].data();
 }
 
 } // namespace ptamd

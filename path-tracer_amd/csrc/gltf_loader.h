@@ -21,7 +21,13 @@ struct Model {
     uint32_t num_faces() const { return (uint32_t)group.size(); }
 };
 
-// Throws std::runtime_error with the reference's messages where it has them.
-void load_gltf(const std::string& path, Model& out);
+enum : uint32_t {
+    kLoadNodeTransforms = 1u, // apply the glTF scene graph (the reference ignores it, ModelLoader.h:204-206)
+    kLoadObj = 2u,            // accept Wavefront .obj files (the reference rejects them, ModelLoader.h:139-142)
+};
+
+// Throws std::runtime_error with the reference's messages where it has them. flags = 0 is the reference's loader.
+void load_gltf(const std::string& path, Model& out, uint32_t flags = 0);
+void load_obj(const std::string& path, Model& out);
 
 } // namespace ptamd

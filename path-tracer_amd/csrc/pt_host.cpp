@@ -520,12 +520,15 @@ int ptamd_scene_commit(ptamd_scene* s)
 }
 
 // ------------------------------------------------------------------------------- model
-int ptamd_model_load(const char* path, ptamd_model** out)
+int ptamd_model_load(const char* path, ptamd_model** out) { return ptamd_model_load_ex(path, 0u, out); }
+int ptamd_model_load_ex(const char* path, uint32_t flags, ptamd_model** out)
 {
     if (!path || !out) return fail(PTAMD_ERR_ARG, "null argument");
+    if (flags & ~(PTAMD_LOAD_NODE_TRANSFORMS | PTAMD_LOAD_OBJ)) return fail(PTAMD_ERR_ARG, "unknown load flag");
+    static_assert(PTAMD_LOAD_NODE_TRANSFORMS == kLoadNodeTransforms && PTAMD_LOAD_OBJ == kLoadObj, "flag values");
     auto m = std::make_unique<ptamd_model>();
     try {
-        load_gltf(path, m->model);
+        load_gltf(path, m->model, flags);
     } catch (const std::exception& e) {
         return fail(PTAMD_ERR_IO, e.what());
     }

@@ -101,12 +101,13 @@ private:
 
 class Mesh : public RayObject {
 public:
-    // Mesh.cpp:7-13: loads the model at construction and throws what the loader throws.
-    Mesh(const std::string& filePath, std::string name) : mPath(filePath)
+    // Mesh.cpp:7-13: loads the model at construction and throws what the loader throws. loadFlags (PTAMD_LOAD_*)
+    // turn on loader options the reference does not have; 0 is the reference's loader.
+    Mesh(const std::string& filePath, std::string name, uint32_t loadFlags = 0) : mPath(filePath)
     {
         mName = std::move(name);
         ptamd_model* m = nullptr;
-        check(ptamd_model_load(filePath.c_str(), &m));
+        check(ptamd_model_load_ex(filePath.c_str(), loadFlags, &m));
         mModel.reset(m, ptamd_model_free);
         ptamd_mesh_desc d;
         check(ptamd_model_desc(m, &d));

@@ -10,7 +10,8 @@
 //   sphere px py pz r <mat> | box px py pz rx ry rz sx sy sz <mat> | mesh path px py pz rx ry rz sx sy sz
 //   <mat> = albedo(3) roughness metallic emissionColour(3) emissionStrength IOR transmission
 //   skybox file.rgba8 N intensity   (6 faces of N x N RGBA8, +x -x +y -y +z -z; not a feature of the reference)
-// --rr turns Russian roulette on (also not in the reference; off by default).
+// --rr turns Russian roulette on (also not in the reference; off by default). --node-transforms applies the glTF
+// scene graph of mesh files and --obj accepts Wavefront .obj meshes (the reference does neither).
 // --frames renders one sample per pixel per launch, as the reference's main loop does (main.cpp:565-569);
 // the default renders all samples in one launch. Both give the same image bit for bit.
 #include <chrono>
@@ -38,12 +39,12 @@ static Material ReadMaterial(std::istream& in)
 int main(int argc, char** argv)
 {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: ptamd_cli <scene.txt> --out image.png [--spp N] [--depth D] [--albedo] [--seed S] [--device I] [--pfm f] [--raw prefix] [--linear] [--no-tonemap] [--frames] [--rr]\n");
+        std::fprintf(stderr, "usage: ptamd_cli <scene.txt> --out image.png [--spp N] [--depth D] [--albedo] [--seed S] [--device I] [--pfm f] [--raw prefix] [--linear] [--no-tonemap] [--frames] [--rr] [--node-transforms] [--obj]\n");
         return 2;
     }
     std::string scenePath = argv[1], outPng, outPfm, outRaw;
     int spp = 64, depth = 10, device = 0;
-    uint32_t seed = 0x5EED;
+    uint32_t seed = 0x5EED, loadFlags = 0;
     bool albedo = false, linear = false, noTonemap = false, frames = false, roulette = false;
     for (int i = 2; i < argc; ++i) {
         std::string a = argv[i];
@@ -60,6 +61,8 @@ int main(int argc, char** argv)
         else if (a == "--no-tonemap") noTonemap = true;
         else if (a == "--frames") frames = true;
         else if (a == "--rr") roulette = true;
+        else if (a == "--node-transforms") loadFlags |= PTAMD_LOAD_NODE_TRANSFORMS;
+        else if (a == "--obj") loadFlags |= PTAMD_LOAD_OBJ;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     try {
@@ -105,7 +108,7 @@ int main(int argc, char** argv)
                 pathTracer.AddRayObject(o);
             } else if (kind == "mesh") {
                 std::string mp; vec3 p, r, s; in >> mp >> p.x >> p.y >> p.z >> r.x >> r.y >> r.z >> s.x >> s.y >> s.z;
-                auto o = std::make_shared<Mesh>(mp, "Mesh");
+                auto o = std::make_shared<Mesh>(mp, "Mesh", loadFlags);
                 o->SetPosition(p); o->SetRotation(r); o->SetScale(s);
                 pathTracer.AddRayObject(o);
             } else throw std::runtime_error("unknown scene record '" + kind + "'");

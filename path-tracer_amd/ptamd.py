@@ -72,7 +72,7 @@ EXPORTS = [
     "ptamd_scene_object_count", "ptamd_scene_add_sphere", "ptamd_scene_add_box", "ptamd_scene_add_mesh",
     "ptamd_scene_add_mesh_file", "ptamd_scene_set_transform", "ptamd_scene_set_radius",
     "ptamd_scene_set_material", "ptamd_scene_set_mesh_group", "ptamd_scene_set_background", "ptamd_scene_set_skybox",
-    "ptamd_scene_commit", "ptamd_model_load", "ptamd_model_desc", "ptamd_model_group_name", "ptamd_model_free",
+    "ptamd_scene_commit", "ptamd_model_load", "ptamd_model_load_ex", "ptamd_model_desc", "ptamd_model_group_name", "ptamd_model_free",
     "ptamd_film_create", "ptamd_film_create_external", "ptamd_film_destroy", "ptamd_film_resize",
     "ptamd_film_reset", "ptamd_film_size", "ptamd_film_read", "ptamd_film_average",
     "ptamd_film_resolve_rgba8", "ptamd_film_device_ptrs", "ptamd_render", "ptamd_render_stats",
@@ -119,6 +119,7 @@ def lib():
         L.ptamd_scene_set_skybox.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.c_float]
         L.ptamd_scene_commit.argtypes = [vp]
         L.ptamd_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.ptamd_model_load_ex.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(vp)]
         L.ptamd_model_desc.argtypes = [vp, C.POINTER(CMeshDesc)]
         L.ptamd_model_group_name.argtypes = [vp, C.c_uint32]
         L.ptamd_model_group_name.restype = C.c_char_p
@@ -293,13 +294,15 @@ class Mesh(RayObject):
     """Mesh.h:11-63: constructed from a .glb/.gltf path (Mesh.cpp:7-13) or from triangle arrays
     (dict with positions (F,9), normals, uvs (F,6), group (F,), groups [pbr dicts], images [(H,W,C) uint8])."""
 
-    def __init__(self, file_path=None, name="Mesh", data=None):
+    def __init__(self, file_path=None, name="Mesh", data=None, node_transforms=False, allow_obj=False):
         super().__init__(name)
         self.mScale = (1.0, 1.0, 1.0)
         self._path = file_path
         self._data = data
         if file_path is None and data is None:
             raise PtamdError("Mesh needs a file path or triangle data")
+        if data is None and (node_transforms or allow_obj):  # loader options the reference does not have
+            self._data = load_model(file_path, node_transforms=node_transforms, allow_obj=allow_obj)
 
     def SetScale(self, s):
         self.mScale = tuple(s)
@@ -567,10 +570,16 @@ def build_scene(scene, mesh_data=None):
     return pt, cam
 
 
-def load_model(path):
-    """ModelLoader(path) through the C ABI: returns the triangle dict used by Mesh(data=...)."""
+LOAD_NODE_TRANSFORMS = 1
+LOAD_OBJ = 2
+
+
+def load_model(path, node_transforms=False, allow_obj=False):
+    """ModelLoader(path) through the C ABI: returns the triangle dict used by Mesh(data=...). The two options are
+    not in the reference: applying the glTF scene graph, and reading Wavefront .obj files."""
     h = C.c_void_p()
-    check(lib().ptamd_model_load(path.encode(), C.byref(h)))
+    flags = (LOAD_NODE_TRANSFORMS if node_transforms else 0) | (LOAD_OBJ if allow_obj else 0)
+    check(lib().ptamd_model_load_ex(path.encode(), flags, C.byref(h)))
     try:
         d = CMeshDesc()
         check(lib().ptamd_model_desc(h, C.byref(d)))

@@ -83,11 +83,13 @@ def png_decode(data):
 
 
 # ----------------------------------------------------------------------------- writer
-def write_glb(path, primitives, materials, images=None):
+def write_glb(path, primitives, materials, images=None, nodes=None, scene_nodes=None):
     """primitives: list of dicts {positions (V,3) f32, normals (V,3) f32|None, uvs (V,2) f32|None,
     indices (T*3,) u32, material: index|None}; each primitive becomes its own glTF mesh.
     materials: list of glTF material dicts (already in glTF JSON form, textures by image index are
-    wired here: any {"index": i} refers to textures[i] == images[i]).  images: list of (H,W,C) uint8."""
+    wired here: any {"index": i} refers to textures[i] == images[i]).  images: list of (H,W,C) uint8.
+    nodes / scene_nodes: an explicit scene graph in glTF JSON form (node dicts with mesh / children / matrix or
+    translation, rotation, scale; root indices); by default one untransformed node per mesh."""
     blob = bytearray()
     views, accessors, meshes = [], [], []
 
@@ -123,8 +125,8 @@ def write_glb(path, primitives, materials, images=None):
         meshes.append({"primitives": [prim]})
 
     doc = {"asset": {"version": "2.0", "generator": "ptamd scenes/gltf_io.py"},
-           "scene": 0, "scenes": [{"nodes": list(range(len(meshes)))}],
-           "nodes": [{"mesh": i} for i in range(len(meshes))],
+           "scene": 0, "scenes": [{"nodes": list(range(len(meshes))) if nodes is None else list(scene_nodes)}],
+           "nodes": [{"mesh": i} for i in range(len(meshes))] if nodes is None else nodes,
            "meshes": meshes, "accessors": accessors, "bufferViews": views}
     if materials:
         doc["materials"] = materials

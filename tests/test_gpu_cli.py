@@ -65,3 +65,41 @@ def test_cli_skybox_and_roulette(gpu, tmp_path):
                    check=True, capture_output=True, text=True, cwd=ROOT)
     a = np.fromfile(str(tmp_path / "raw.accum.f32"), np.float32).reshape(48, 64, 3)
     assert np.array_equal(a.view(np.uint32), film.Accum().view(np.uint32))
+
+
+def test_cli_obj_and_node_transforms(gpu, tmp_path):
+    """--obj and --node-transforms reach the loader: an OBJ quad lit by an emissive OBJ triangle renders the same
+    film as the Python mirror given the same options, and differs from the untransformed load of a glTF whose
+    only node is translated."""
+    (tmp_path / "m.mtl").write_text("newmtl wall\nKd 0.7 0.7 0.7\nnewmtl lamp\nKd 0 0 0\nKe 3 3 3\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 5\nv 5.5 0 5\nv 5.5 5.5 5\nv 0 5.5 5\nv 2 5 3\nv 3.5 5 3\nv 2.7 5 4.5\n"
+                                    "usemtl wall\nf 1 2 3 4\nusemtl lamp\nf 5 6 7\n")
+    cam = presets.default_camera()
+    scene_txt = "film 48 40\ncamera %s %s %g\nmesh %s 0 0 0 0 0 0 1 1 1\n" % (
+        " ".join("%.9g" % v for v in cam["pos"]), " ".join("%.9g" % v for v in cam["rot"]), cam["fov"], tmp_path / "m.obj")
+    (tmp_path / "s.txt").write_text(scene_txt)
+    bad = subprocess.run([CLI, str(tmp_path / "s.txt"), "--raw", str(tmp_path / "r0")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "only supports .glb/.gltf" in bad.stderr
+    subprocess.run([CLI, str(tmp_path / "s.txt"), "--raw", str(tmp_path / "r1"), "--spp", "4", "--depth", "3", "--obj"], check=True, capture_output=True)
+    a = np.fromfile(str(tmp_path / "r1.accum.f32"), np.float32).reshape(40, 48, 3)
+    pt = gpu.PathTracer()
+    m = gpu.Mesh(str(tmp_path / "m.obj"), allow_obj=True)
+    pt.AddRayObject(m)
+    pt.Commit()
+    c = gpu.Camera((48, 40), cam["pos"], cam["rot"]); c.SetFov(cam["fov"])
+    film = gpu.Film(48, 40)
+    gpu.Render(c, pt, film, 4, 3)
+    assert np.array_equal(film.Accum().view(np.uint32), a.view(np.uint32))
+    assert a.max() > 0.5  # the lamp is seen
+
+    prim = gltf_io.box_primitive((0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    glb = str(tmp_path / "n.glb")
+    gltf_io.write_glb(glb, [prim], [gltf_io.gltf_material("m", presets.material(albedo=(0.9, 0.2, 0.2)))],
+                      nodes=[{"mesh": 0, "translation": [2.78, 2.73, 2.0], "scale": [2, 2, 2]}], scene_nodes=[0])
+    (tmp_path / "s2.txt").write_text(scene_txt.replace(str(tmp_path / "m.obj"), glb))
+    outs = []
+    for extra in ([], ["--node-transforms"]):
+        subprocess.run([CLI, str(tmp_path / "s2.txt"), "--raw", str(tmp_path / "r2"), "--spp", "1", "--depth", "1", "--albedo"] + extra, check=True, capture_output=True)
+        outs.append(np.fromfile(str(tmp_path / "r2.accum.f32"), np.float32).reshape(40, 48, 3))
+    red = lambda img: int(((img[12:28, 16:32, 0] > 0.3) & (img[12:28, 16:32, 1] < 0.3)).sum())  # centre of the view
+    assert red(outs[0]) == 0 and red(outs[1]) > 50  # stored at the origin the box is off-centre; its node moves it in front of the camera

@@ -1,0 +1,102 @@
+"""Loader options that go beyond the reference (it ignores glTF nodes, ModelLoader.h:204-206, and rejects
+anything but .glb/.gltf, ModelLoader.h:139-142). No reference output exists for them: the expected values are
+computed independently here with numpy. Host code only, no GPU needed."""
+import numpy as np
+import pytest
+
+import ptamd
+from scenes import gltf_io
+
+
+def quat_matrix(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def trs(t=(0, 0, 0), q=(0, 0, 0, 1), s=(1, 1, 1)):
+    M = np.eye(4)
+    M[:3, :3] = quat_matrix(q) @ np.diag(s)
+    M[:3, 3] = t
+    return M
+
+
+def soup(prim):
+    idx = prim["indices"].reshape(-1, 3)
+    return prim["positions"][idx].astype(np.float64), prim["normals"][idx].astype(np.float64)
+
+
+def apply(M, P, N):
+    P2 = P @ M[:3, :3].T + M[:3, 3]
+    N2 = N @ np.linalg.inv(M[:3, :3])  # rows times inverse = inverse-transpose applied to column vectors
+    N2 /= np.linalg.norm(N2, axis=-1, keepdims=True)
+    return P2, N2
+
+
+def test_node_transforms_hierarchy_trs_matrix_and_instancing(tmp_path):
+    a = gltf_io.box_primitive((0, 0, 0), (0, 0, 0), (1, 2, 3), 0)
+    b = gltf_io.bumpy_sphere_primitive(6, 8, radius=0.5, material_index=1)
+    mats = [gltf_io.gltf_material("a", [0.8, 0.2, 0.2, 0.5, 0.0, 1, 1, 1, 0.0, 1.5, 0.0]),
+            gltf_io.gltf_material("b", [0.2, 0.8, 0.2, 0.5, 0.0, 1, 1, 1, 0.0, 1.5, 0.0])]
+    h = np.sqrt(0.5)
+    root = trs(t=(1, 2, 3), q=(0, h, 0, h), s=(2, 2, 2))           # 90 degrees about y, uniform scale
+    child = trs(t=(0, 1, 0), q=(h, 0, 0, h), s=(1, 0.5, 2))        # non-uniform scale under a rotation
+    other = np.array([[0, -1, 0, 4], [1, 0, 0, 0], [0, 0, 3, -2], [0, 0, 0, 1]], float)
+    nodes = [{"translation": [1, 2, 3], "rotation": [0, h, 0, h], "scale": [2, 2, 2], "mesh": 0, "children": [1]},
+             {"translation": [0, 1, 0], "rotation": [h, 0, 0, h], "scale": [1, 0.5, 2], "mesh": 1},
+             {"matrix": [float(v) for v in other.T.reshape(-1)], "mesh": 1},   # column-major, second instance of mesh 1
+             {"mesh": 0}]                                                       # not in the scene: must not appear
+    path = str(tmp_path / "nodes.glb")
+    gltf_io.write_glb(path, [a, b], mats, nodes=nodes, scene_nodes=[0, 2])
+    flat = ptamd.load_model(path)                       # the reference's behaviour: meshes as stored, once each
+    assert flat["positions"].shape[0] == 12 + len(b["indices"]) // 3
+    Pa, Na = soup(a)
+    Pb, Nb = soup(b)
+    assert np.array_equal(flat["positions"][:12].reshape(-1, 3, 3), Pa.astype(np.float32))
+    got = ptamd.load_model(path, node_transforms=True)
+    nb = len(b["indices"]) // 3
+    assert got["positions"].shape[0] == 12 + 2 * nb
+    want = [apply(root, Pa, Na), apply(root @ child, Pb, Nb), apply(other, Pb, Nb)]
+    P = np.concatenate([w[0] for w in want]).reshape(-1, 9)
+    N = np.concatenate([w[1] for w in want]).reshape(-1, 9)
+    assert np.abs(got["positions"] - P).max() <= 1e-5
+    assert np.abs(got["normals"] - N).max() <= 1e-5
+    assert list(got["group"]) == [0] * 12 + [1] * (2 * nb)
+    assert [g["name"] for g in got["groups"]] == ["a", "b"]
+
+
+def test_obj_reader(tmp_path):
+    (tmp_path / "m.mtl").write_text(
+        "newmtl red\nKd 0.8 0.1 0.1\nPr 0.3\nPm 0.0\n"
+        "newmtl lamp\nKd 0 0 0\nKe 2 2 1\nNi 1.33\nd 0.25\nNs 98\n")
+    (tmp_path / "m.obj").write_text(
+        "# quad + triangle\nmtllib m.mtl\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "vn 0 0 1\n"
+        "usemtl red\nf 1/1/1 2/2/1 3/3/1 4/4/1\n"
+        "usemtl lamp\nf -1 -5 -4\n"
+        "usemtl red\nf 1//1 3//1 5//1\n")
+    with pytest.raises(ptamd.PtamdError, match="only supports .glb/.gltf"):
+        ptamd.load_model(str(tmp_path / "m.obj"))          # the reference's behaviour stays the default
+    m = ptamd.load_model(str(tmp_path / "m.obj"), allow_obj=True)
+    assert m["positions"].shape == (4, 9)
+    V = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    assert np.array_equal(m["positions"].reshape(-1, 3, 3), V[[[0, 1, 2], [0, 2, 3], [4, 0, 1], [0, 2, 4]]])
+    assert np.array_equal(m["uvs"][0], np.array([0, 0, 1, 0, 1, 1], np.float32)) and np.all(m["uvs"][2:] == 0)
+    assert np.all(m["normals"][:2].reshape(-1, 3) == (0, 0, 1))
+    n = np.cross(V[0] - V[4], V[1] - V[4]); n /= np.linalg.norm(n)  # face without normals: geometric normal
+    assert np.allclose(m["normals"][2].reshape(3, 3), n, atol=1e-6)
+    assert list(m["group"]) == [0, 0, 1, 0] and [g["name"] for g in m["groups"]] == ["red", "lamp"]
+    red, lamp = m["groups"]
+    assert np.allclose(red["base_color_factor"][:3], (0.8, 0.1, 0.1)) and abs(red["roughness_factor"] - 0.3) < 1e-6 and red["metallic_factor"] == 0
+    assert np.allclose(lamp["emissive_factor"], (2, 2, 1)) and abs(lamp["ior"] - 1.33) < 1e-6
+    assert abs(lamp["transmission_factor"] - 0.75) < 1e-6 and abs(lamp["roughness_factor"] - np.sqrt(2 / 100)) < 1e-6
+
+
+def test_load_flags_are_validated():
+    L = ptamd.lib()
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.ptamd_model_load_ex(b"x.glb", 8, C.byref(h)) == -1 and b"unknown load flag" in L.ptamd_last_error()
