@@ -145,30 +145,32 @@ PT_DEV f3 xform_normal(const float* minv, f3 n)
     return mk3(minv[0] * n.x + minv[4] * n.y + minv[8] * n.z, minv[1] * n.x + minv[5] * n.y + minv[9] * n.z, minv[2] * n.x + minv[6] * n.y + minv[10] * n.z);
 }
 
-// Mesh::RayTriMT (Mesh.cpp:418-445) on the precomputed v0,e1,e2.
-PT_DEV bool tri_test(const float4* __restrict__ tp, uint32_t stride, f3 o, f3 d, float& t, float& u, float& v, int& group)
+// Mesh::RayTriMT (Mesh.cpp:418-445) on the plane form of DTri: same determinant threshold, same t, u, v up to
+// rounding. The distance window of the caller (Mesh.cpp:104) is applied between t and the barycentrics, so a
+// wave whose candidates are all out of range skips the rest. INCLUSIVE: accept t == tHi.
+template <bool INCLUSIVE>
+PT_DEV bool tri_test(const float4* __restrict__ tp, uint32_t stride, f3 o, f3 d, float tLo, float tHi, float& t, float& u, float& v)
 {
     float4 q0 = tp[0], q1 = tp[stride], q2 = tp[2 * stride];
-    group = __float_as_int(q2.y);
-    f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-    f3 p = cross(d, e2);
-    float det = dot(e1, p);
-    if (fabsf(det) < 1e-8f) return false;
-    float invDet = frcp(det);
-    f3 tv = o - v0;
-    u = dot(tv, p) * invDet;
+    f3 n = mk3(q0.x, q0.y, q0.z);
+    float dn = dot(n, d);
+    if (fabsf(dn) < 1e-8f) return false;
+    t = (q0.w - dot(n, o)) * frcp(dn);
+    if (!(t > 1e-8f) || t < tLo || (INCLUSIVE ? t > tHi : t >= tHi)) return false;
+    f3 h = o + d * t;
+    u = dot(mk3(q1.x, q1.y, q1.z), h) + q1.w;
     if (u < 0.0f || u > 1.0f) return false;
-    f3 q = cross(tv, e1);
-    v = dot(d, q) * invDet;
-    if (v < 0.0f || u + v > 1.0f) return false;
-    t = dot(e2, q) * invDet;
-    return t > 1e-8f;
+    v = dot(mk3(q2.x, q2.y, q2.z), h) + q2.w;
+    return !(v < 0.0f || u + v > 1.0f);
 }
 
 PT_DEV float4 sample_nearest(const DScene& sc, int img, float u, float v);
 // Alpha MASK cutout (Mesh.cpp:106-125): false when the texel is below the cutoff.
-PT_DEV bool alpha_pass(const DScene& sc, const DMesh& me, int tri, int group, float u, float v)
+PT_DEV bool alpha_pass(const DScene& sc, const DMesh& me, int tri, float u, float v)
 {
+    const float4* sh = sc.shade + ((size_t)me.tri_base + (size_t)tri) * 7;
+    const int group = __float_as_int(sh[6].x);
+    if (group < 0) return true;
     const DPbr& g = sc.groups[me.group_base + group];
     if (g.alpha_mode != 1) return true;
     float alpha = g.base_color_factor[3];
@@ -252,10 +254,9 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
             uint32_t first = code >> 3, cnt_tris = (code & 7u) + 1u;
             for (uint32_t i = 0; i < cnt_tris; ++i) {
                 if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
-                float t, u, v; int group;
-                if (!tri_test(tris + (size_t)(first + i) * tstep, ts, o, d, t, u, v, group)) continue;
-                if (t < tMinObj || t >= closestT) continue; // Mesh.cpp:104
-                if ((me.flags & 1u) && group >= 0 && !alpha_pass(sc, me, (int)(first + i), group, u, v)) continue; // Mesh.cpp:106-125
+                float t, u, v;
+                if (!tri_test<false>(tris + (size_t)(first + i) * tstep, ts, o, d, tMinObj, closestT, t, u, v)) continue; // Mesh.cpp:104
+                if ((me.flags & 1u) && !alpha_pass(sc, me, (int)(first + i), u, v)) continue; // Mesh.cpp:106-125
                 closestT = t; bestTri = (int)(first + i); bu = u; bv = v;
             }
             pop();
@@ -389,10 +390,9 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
             uint32_t first = code >> 3, cnt_tris = (code & 7u) + 1u;
             for (uint32_t i = 0; i < cnt_tris; ++i) {
                 if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
-                float t, u, v; int group;
-                if (!tri_test(tris + (size_t)(first + i) * tstep, ts, o, d, t, u, v, group)) continue;
-                if (t < tMinObj || t > bound) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
-                if ((me.flags & 1u) && group >= 0 && !alpha_pass(sc, me, (int)(first + i), group, u, v)) continue; // Mesh.cpp:106-125
+                float t, u, v;
+                if (!tri_test<true>(tris + (size_t)(first + i) * tstep, ts, o, d, tMinObj, bound, t, u, v)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
+                if ((me.flags & 1u) && !alpha_pass(sc, me, (int)(first + i), u, v)) continue; // Mesh.cpp:106-125
                 bound = t;
                 atomicMin(&coop.res[waveBase + owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(first + i + 1u));
             }
@@ -438,8 +438,8 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
                 tri = mesh_traverse_coop<BLOCK, COUNT>(sc, geom, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt);
                 if (!valid) tri = -1;
                 if (tri >= 0) { // barycentrics of the winner: its test repeated on this lane's own ray
-                    float tt; int gg;
-                    (void)tri_test(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, 1u, oo, dd, tt, u, v, gg);
+                    float tt;
+                    (void)tri_test<true>(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, 1u, oo, dd, 0.0f, 3.0e38f, tt, u, v);
                 }
             } else {
                 mesh_traverse<BLOCK, COUNT>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt);

@@ -441,10 +441,21 @@ int ptamd_scene_commit(ptamd_scene* s)
                     uint32_t f = hm.bvh.order[i];
                     const float* p = &md.positions[9 * (size_t)f];
                     DTri t; std::memset(&t, 0, sizeof t);
-                    t.v0[0] = p[0]; t.v0[1] = p[1]; t.v0[2] = p[2];
-                    t.e1x = p[3] - p[0]; t.e1yz[0] = p[4] - p[1]; t.e1yz[1] = p[5] - p[2];
-                    t.e2xy[0] = p[6] - p[0]; t.e2xy[1] = p[7] - p[1]; t.e2z = p[8] - p[2];
-                    t.group = md.group[f];
+                    {
+                        const double v0[3] = { p[0], p[1], p[2] };
+                        const double e1[3] = { (double)(p[3] - p[0]), (double)(p[4] - p[1]), (double)(p[5] - p[2]) }; // float differences, as Mesh.cpp:421-422 forms them
+                        const double e2[3] = { (double)(p[6] - p[0]), (double)(p[7] - p[1]), (double)(p[8] - p[2]) };
+                        const double n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+                        const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                        if (nn > 0.0) {
+                            const double m1[3] = { (e2[1] * n[2] - e2[2] * n[1]) / nn, (e2[2] * n[0] - e2[0] * n[2]) / nn, (e2[0] * n[1] - e2[1] * n[0]) / nn };
+                            const double m2[3] = { (n[1] * e1[2] - n[2] * e1[1]) / nn, (n[2] * e1[0] - n[0] * e1[2]) / nn, (n[0] * e1[1] - n[1] * e1[0]) / nn };
+                            for (int k = 0; k < 3; ++k) { t.n[k] = (float)n[k]; t.m1[k] = (float)m1[k]; t.m2[k] = (float)m2[k]; }
+                            t.nv0 = (float)(n[0] * v0[0] + n[1] * v0[1] + n[2] * v0[2]);
+                            t.d1 = (float)-(m1[0] * v0[0] + m1[1] * v0[1] + m1[2] * v0[2]);
+                            t.d2 = (float)-(m2[0] * v0[0] + m2[1] * v0[1] + m2[2] * v0[2]);
+                        } // a degenerate triangle keeps n = 0: the determinant test rejects it
+                    }
                     tris.push_back(t);
                     DShade sh; std::memset(&sh, 0, sizeof sh);
                     std::memcpy(sh.pa, p, 36);
