@@ -538,10 +538,10 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
         f3 nObj = normalize((na * w + nb * u) + nc * v);
         f3 nObjG = normalize(cross(pb - pa, pc - pa));
         float tu = w * s4.z + u * s5.x + v * s5.z, tv = w * s4.w + u * s5.y + v * s5.w;
-        int group = __float_as_int(s6.x);
         p = xform_point(me.m, pObj);
-        matIndex = 0; // slot 0 = Material{} defaults (Mesh.cpp:242-246)
-        if (group >= 0) {
+        matIndex = __float_as_int(s6.y); // constant material slot of the face, or -1 (Mesh.cpp:242-246: slot 0 = Material{} defaults)
+        if (matIndex < 0) {
+            const int group = __float_as_int(s6.x);
             const DPbr& g = sc.groups[me.group_base + group];
             if (g.normal_tex >= 0) { // Mesh.cpp:174-226
                 f3 dp1 = pb - pa, dp2 = pc - pa;
@@ -564,7 +564,7 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
             }
             bool textured = (g.base_color_tex >= 0) | (g.metallic_roughness_tex >= 0) | (g.emissive_tex >= 0) | (g.transmission_tex >= 0);
             if (textured) fill_material_textured(sc, g, tu, tv, h);
-            matIndex = textured ? -1 : g.material; // untextured groups: constant material slot
+            else matIndex = g.material; // normal map only: constant material slot
         }
         f3 nW = normalize(xform_normal(me.minv, nObj));
         f3 ngW = normalize(xform_normal(me.minv, nObjG));

@@ -437,6 +437,26 @@ int ptamd_scene_commit(ptamd_scene* s)
                 ms.node_base = (uint32_t)nodes.size(); ms.tri_base = (uint32_t)tris.size();
                 ms.group_base = (uint32_t)groups.size(); ms.image_base = (uint32_t)images.size(); ms.flags = 0;
                 nodes.insert(nodes.end(), hm.bvh.nodes.begin(), hm.bvh.nodes.end());
+                std::vector<int32_t> faceMaterial; // per group: constant material slot, or -1 when the group samples images
+                for (const ptamd_pbr& g : md.groups) {
+                    DPbr dg; std::memset(&dg, 0, sizeof dg);
+                    auto img = [&](int32_t t) { return t >= 0 ? (int32_t)(ms.image_base + (uint32_t)t) : -1; };
+                    dg.base_color_tex = img(g.base_color_tex); dg.normal_tex = img(g.normal_tex);
+                    dg.metallic_roughness_tex = img(g.metallic_roughness_tex); dg.emissive_tex = img(g.emissive_tex);
+                    dg.transmission_tex = img(g.transmission_tex);
+                    dg.alpha_mode = g.alpha_mode; dg.alpha_cutoff = g.alpha_cutoff; dg.normal_scale = g.normal_scale;
+                    std::memcpy(dg.base_color_factor, g.base_color_factor, 16);
+                    std::memcpy(dg.emissive_factor, g.emissive_factor, 12);
+                    dg.metallic_factor = g.metallic_factor; dg.roughness_factor = g.roughness_factor;
+                    dg.transmission_factor = g.transmission_factor; dg.ior = g.ior;
+                    dg.material = (int32_t)materials.size();
+                    materials.push_back(to_dmaterial(group_material(g)));
+                    if (g.alpha_mode == 1) ms.flags |= 1u;
+                    const bool textured = g.base_color_tex >= 0 || g.metallic_roughness_tex >= 0 || g.emissive_tex >= 0 || g.transmission_tex >= 0;
+                    if (textured || g.normal_tex >= 0) ms.flags |= 2u;
+                    groups.push_back(dg);
+                    faceMaterial.push_back((textured || g.normal_tex >= 0) ? -1 : dg.material);
+                }
                 for (uint32_t i = 0; i < md.num_faces(); ++i) {
                     uint32_t f = hm.bvh.order[i];
                     const float* p = &md.positions[9 * (size_t)f];
@@ -462,29 +482,13 @@ int ptamd_scene_commit(ptamd_scene* s)
                     std::memcpy(sh.na, &md.normals[9 * (size_t)f], 36);
                     std::memcpy(sh.ta, &md.texcoords[6 * (size_t)f], 24);
                     sh.group = md.group[f];
+                    sh.material = md.group[f] >= 0 ? faceMaterial[(size_t)md.group[f]] : 0;
                     shade.push_back(sh);
                 }
                 for (size_t i = 0; i < md.images.size(); ++i) {
                     DImage di; di.width = md.images[i].width; di.height = md.images[i].height; di.offset = (uint32_t)texels.size(); di.pad = 0;
                     texels.insert(texels.end(), md.image_data[i].begin(), md.image_data[i].end());
                     images.push_back(di);
-                }
-                for (const ptamd_pbr& g : md.groups) {
-                    DPbr dg; std::memset(&dg, 0, sizeof dg);
-                    auto img = [&](int32_t t) { return t >= 0 ? (int32_t)(ms.image_base + (uint32_t)t) : -1; };
-                    dg.base_color_tex = img(g.base_color_tex); dg.normal_tex = img(g.normal_tex);
-                    dg.metallic_roughness_tex = img(g.metallic_roughness_tex); dg.emissive_tex = img(g.emissive_tex);
-                    dg.transmission_tex = img(g.transmission_tex);
-                    dg.alpha_mode = g.alpha_mode; dg.alpha_cutoff = g.alpha_cutoff; dg.normal_scale = g.normal_scale;
-                    std::memcpy(dg.base_color_factor, g.base_color_factor, 16);
-                    std::memcpy(dg.emissive_factor, g.emissive_factor, 12);
-                    dg.metallic_factor = g.metallic_factor; dg.roughness_factor = g.roughness_factor;
-                    dg.transmission_factor = g.transmission_factor; dg.ior = g.ior;
-                    dg.material = (int32_t)materials.size();
-                    materials.push_back(to_dmaterial(group_material(g)));
-                    if (g.alpha_mode == 1) ms.flags |= 1u;
-                    if (g.base_color_tex >= 0 || g.normal_tex >= 0 || g.metallic_roughness_tex >= 0 || g.emissive_tex >= 0 || g.transmission_tex >= 0) ms.flags |= 2u;
-                    groups.push_back(dg);
                 }
                 uploaded.emplace_back(&hm, (uint32_t)slots.size());
                 slots.push_back(ms);

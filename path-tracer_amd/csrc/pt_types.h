@@ -72,7 +72,9 @@ struct DShade {
     float na[3], nb[3], nc[3];
     float ta[2], tb[2], tc[2];
     int32_t group;
-    float pad[3];
+    int32_t material;  // >= 0: constant material slot of the face (group without textures, or no group: slot 0), so the
+                       // hit fill skips the group record; -1: the group samples textures or a normal map
+    float pad[2];
 };
 static_assert(sizeof(DShade) == 112, "DShade is 7 float4");
 
