@@ -149,9 +149,9 @@ PT_DEV f3 xform_normal(const float* minv, f3 n)
 // rounding. The distance window of the caller (Mesh.cpp:104) is applied between t and the barycentrics, so a
 // wave whose candidates are all out of range skips the rest. INCLUSIVE: accept t == tHi.
 template <bool INCLUSIVE>
-PT_DEV bool tri_test(const float4* __restrict__ tp, uint32_t stride, f3 o, f3 d, float tLo, float tHi, float& t, float& u, float& v)
+PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float tHi, float& t, float& u, float& v)
 {
-    float4 q0 = tp[0], q1 = tp[stride], q2 = tp[2 * stride];
+    float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     f3 n = mk3(q0.x, q0.y, q0.z);
     float dn = dot(n, d);
     if (fabsf(dn) < 1e-8f) return false;
@@ -184,13 +184,9 @@ PT_DEV bool alpha_pass(const DScene& sc, const DMesh& me, int tri, float u, floa
     return !(alpha < g.alpha_cutoff);
 }
 
-// Where the traversal reads BVH nodes and hot triangles from: the global arrays of the scene, or a copy of
-// them that the workgroup staged into LDS (scenes of a few KB). Indexing is identical in both.
-// node_stride / tri_stride: distance in float4 between the k-th and (k+1)-th float4 of one record; records are
-// node_step / tri_step float4 apart. Global memory keeps records contiguous (stride 1, step 4 or 3: one cache
-// line per record); the LDS copy is column-major (stride = record count, step 1) so that the 16-byte reads of
-// lanes holding different records spread over all banks instead of the 4 bank groups a 64-byte pitch allows.
-struct Geom { const float4* nodes; const float4* tris; uint32_t node_stride, node_step, tri_stride, tri_step; };
+// Where the traversal reads BVH nodes (4 float4 each) and hot triangles (3 float4 each) from: the global arrays of
+// the scene, or a copy of them that the workgroup staged into LDS (scenes of a few KB). Same layout in both.
+struct Geom { const float4* nodes; const float4* tris; };
 
 // Iterative BVH traversal (replaces the stack walk of Mesh.cpp:79-149), "while-while" form: all lanes of a
 // wave first descend through inner nodes until each holds a leaf (or has run out of work), then all of them
@@ -209,9 +205,8 @@ template <int BLOCK, bool COUNT>
 PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f3 o, f3 d, float tMinObj, float& closestT,
                           int& bestTri, float& bu, float& bv, StackEntry* __restrict__ stack, int slot, TraversalCounts& cnt)
 {
-    const float4* __restrict__ nodes = geom.nodes + (size_t)me.node_base * geom.node_step;
-    const float4* __restrict__ tris = geom.tris + (size_t)me.tri_base * geom.tri_step;
-    const uint32_t ns = geom.node_stride, nstep = geom.node_step, ts = geom.tri_stride, tstep = geom.tri_step;
+    const float4* __restrict__ nodes = geom.nodes + (size_t)me.node_base * 4;
+    const float4* __restrict__ tris = geom.tris + (size_t)me.tri_base * 3;
     const float BIG = 1e30f;
     f3 inv = mk3(fabsf(d.x) > 1e-30f ? frcp(d.x) : BIG, fabsf(d.y) > 1e-30f ? frcp(d.y) : BIG, fabsf(d.z) > 1e-30f ? frcp(d.z) : BIG);
     f3 oi = o * inv;
@@ -224,8 +219,8 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
     while (cur != kDone) {
         while ((uint32_t)cur < (uint32_t)kDone) { // inner node
             if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
-            const float4* n = nodes + (size_t)cur * nstep;
-            float4 a = n[0], b = n[ns], c = n[2 * ns], r = n[3 * ns];
+            const float4* n = nodes + (size_t)cur * 4;
+            float4 a = n[0], b = n[1], c = n[2], r = n[3];
             float lx0 = fmaf(a.x, inv.x, -oi.x), lx1 = fmaf(a.w, inv.x, -oi.x);
             float ly0 = fmaf(a.y, inv.y, -oi.y), ly1 = fmaf(b.x, inv.y, -oi.y);
             float lz0 = fmaf(a.z, inv.z, -oi.z), lz1 = fmaf(b.y, inv.z, -oi.z);
@@ -255,7 +250,7 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
             for (uint32_t i = 0; i < cnt_tris; ++i) {
                 if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
                 float t, u, v;
-                if (!tri_test<false>(tris + (size_t)(first + i) * tstep, ts, o, d, tMinObj, closestT, t, u, v)) continue; // Mesh.cpp:104
+                if (!tri_test<false>(tris + (size_t)(first + i) * 3, o, d, tMinObj, closestT, t, u, v)) continue; // Mesh.cpp:104
                 if ((me.flags & 1u) && !alpha_pass(sc, me, (int)(first + i), u, v)) continue; // Mesh.cpp:106-125
                 closestT = t; bestTri = (int)(first + i); bu = u; bv = v;
             }
@@ -301,9 +296,8 @@ template <int BLOCK, bool COUNT>
 PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& me, bool valid, f3 o, f3 d, float tMinObj, float& closestT,
                          StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts& cnt)
 {
-    const float4* __restrict__ nodes = geom.nodes + (size_t)me.node_base * geom.node_step;
-    const float4* __restrict__ tris = geom.tris + (size_t)me.tri_base * geom.tri_step;
-    const uint32_t ns = geom.node_stride, nstep = geom.node_step, ts = geom.tri_stride, tstep = geom.tri_step;
+    const float4* __restrict__ nodes = geom.nodes + (size_t)me.node_base * 4;
+    const float4* __restrict__ tris = geom.tris + (size_t)me.tri_base * 3;
     const float BIG = 1e30f;
     const int lane = slot & 63, waveBase = slot & ~63;
     auto inverse = [&](f3 dir) { return mk3(fabsf(dir.x) > 1e-30f ? frcp(dir.x) : BIG, fabsf(dir.y) > 1e-30f ? frcp(dir.y) : BIG, fabsf(dir.z) > 1e-30f ? frcp(dir.z) : BIG); };
@@ -334,8 +328,8 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
         if (nInner >= nLeaf) {
             if (isInner) {
                 if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
-                const float4* n = nodes + (size_t)cur * nstep;
-                float4 a = n[0], b = n[ns], c = n[2 * ns], r = n[3 * ns];
+                const float4* n = nodes + (size_t)cur * 4;
+                float4 a = n[0], b = n[1], c = n[2], r = n[3];
                 float lx0 = fmaf(a.x, inv.x, -oi.x), lx1 = fmaf(a.w, inv.x, -oi.x);
                 float ly0 = fmaf(a.y, inv.y, -oi.y), ly1 = fmaf(b.x, inv.y, -oi.y);
                 float lz0 = fmaf(a.z, inv.z, -oi.z), lz1 = fmaf(b.y, inv.z, -oi.z);
@@ -391,7 +385,7 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
             for (uint32_t i = 0; i < cnt_tris; ++i) {
                 if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
                 float t, u, v;
-                if (!tri_test<true>(tris + (size_t)(first + i) * tstep, ts, o, d, tMinObj, bound, t, u, v)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
+                if (!tri_test<true>(tris + (size_t)(first + i) * 3, o, d, tMinObj, bound, t, u, v)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
                 if ((me.flags & 1u) && !alpha_pass(sc, me, (int)(first + i), u, v)) continue; // Mesh.cpp:106-125
                 bound = t;
                 atomicMin(&coop.res[waveBase + owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(first + i + 1u));
@@ -439,7 +433,7 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
                 if (!valid) tri = -1;
                 if (tri >= 0) { // barycentrics of the winner: its test repeated on this lane's own ray
                     float tt;
-                    (void)tri_test<true>(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, 1u, oo, dd, 0.0f, 3.0e38f, tt, u, v);
+                    (void)tri_test<true>(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, oo, dd, 0.0f, 3.0e38f, tt, u, v);
                 }
             } else {
                 mesh_traverse<BLOCK, COUNT>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt);

@@ -22,15 +22,15 @@ PT_DEV Geom stage_geometry(const DScene& sc, float4* lds_geom)
 {
     Geom g;
     if (LDS_GEOM) {
-        const uint32_t nn = sc.num_nodes, nt = sc.num_tris, n4 = nn * 4u, t4 = nt * 3u;
-        for (uint32_t i = threadIdx.x; i < n4; i += kBlock) lds_geom[(i & 3u) * nn + (i >> 2)] = sc.nodes[i]; // transpose to column-major
-        for (uint32_t i = threadIdx.x; i < t4; i += kBlock) lds_geom[n4 + (i % 3u) * nt + i / 3u] = sc.tris[i];
+        // records stay contiguous (64-byte nodes, 48-byte triangles): the four 16-byte reads of a node then differ
+        // only in their immediate offset, which measured faster than a bank-spreading column-major copy
+        const uint32_t n4 = sc.num_nodes * 4u, t4 = sc.num_tris * 3u;
+        for (uint32_t i = threadIdx.x; i < n4; i += kBlock) lds_geom[i] = sc.nodes[i];
+        for (uint32_t i = threadIdx.x; i < t4; i += kBlock) lds_geom[n4 + i] = sc.tris[i];
         __syncthreads();
         g.nodes = lds_geom; g.tris = lds_geom + n4;
-        g.node_stride = nn; g.node_step = 1; g.tri_stride = nt; g.tri_step = 1;
     } else {
         g.nodes = sc.nodes; g.tris = sc.tris;
-        g.node_stride = 1; g.node_step = 4; g.tri_stride = 1; g.tri_step = 3;
     }
     return g;
 }
@@ -207,7 +207,6 @@ __global__ __launch_bounds__(kBlock) void closest_hits_kernel(DScene sc, const f
     __shared__ uint32_t coop_mail[kBlock];
     Coop coop; coop.res = coop_res; coop.mail = coop_mail;
     Geom geom; geom.nodes = sc.nodes; geom.tris = sc.tris;
-    geom.node_stride = 1; geom.node_step = 4; geom.tri_stride = 1; geom.tri_step = 3;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     Ray ray;
