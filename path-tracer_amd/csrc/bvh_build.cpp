@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <unordered_map>
 
 namespace ptamd {
 namespace {
@@ -29,7 +30,9 @@ float kCostNode = 1.0f, kCostTri = 1.2f;
 struct Builder {
     std::vector<Box3> fb;
     std::vector<float> fc; // 3 per face
-    std::vector<uint32_t> idx;
+    std::vector<uint32_t> idx;      // primitive indices, permuted by the build
+    std::vector<uint32_t> primA, primB; // faces of each primitive (primB = kNone for a lone triangle)
+    std::vector<uint32_t> slots;    // leaf order -> face
     std::vector<DNode> nodes;
     int maxDepth = 32;
     int depthSeen = 0;
@@ -122,38 +125,111 @@ struct Builder {
     {
         for (int k = 0; k < 3; ++k) { b.lo[k] -= pad; b.hi[k] += pad; }
     }
-    int32_t leaf(uint32_t start, uint32_t count) const { return ~(int32_t)((start << 3) | (count - 1)); }
+    static constexpr uint32_t kNone = 0xFFFFFFFFu;
+    int32_t leaf(uint32_t start, uint32_t count)
+    {
+        uint32_t first = (uint32_t)slots.size(), mask = 0;
+        for (uint32_t i = 0; i < count; ++i) {
+            uint32_t p = idx[start + i];
+            slots.push_back(primA[p]);
+            if (primB[p] != kNone) { slots.push_back(primB[p]); mask |= 1u << i; }
+        }
+        return ~(int32_t)((first << 6) | (mask << 2) | (count - 1));
+    }
 };
 
 } // namespace
 
-BvhResult build_bvh(const float* P, uint32_t n, int max_depth)
+namespace {
+// Pairs triangles that share an edge and form a parallelogram: for A = (a, b, c) the partner must consist of b, c
+// and d = b + c - a (within rounding of the coordinates), in the same material group. Greedy, first match wins.
+void pair_quads(const float* P, const int32_t* group, uint32_t n, float tol, std::vector<uint32_t>& primA, std::vector<uint32_t>& primB,
+                std::vector<int>& rotation)
+{
+    struct Key { uint32_t v[6]; bool operator==(const Key& o) const { return !std::memcmp(v, o.v, sizeof v); } };
+    struct KeyHash { size_t operator()(const Key& k) const { size_t h = 1469598103934665603ull; for (uint32_t x : k.v) h = (h ^ x) * 1099511628211ull; return h; } };
+    auto key_of = [&](const float* p, const float* q) {
+        Key k; uint32_t a[3], b[3];
+        std::memcpy(a, p, 12); std::memcpy(b, q, 12);
+        if (std::memcmp(a, b, 12) > 0) std::swap_ranges(a, a + 3, b);
+        std::memcpy(k.v, a, 12); std::memcpy(k.v + 3, b, 12);
+        return k;
+    };
+    std::unordered_map<Key, std::vector<uint32_t>, KeyHash> edges;
+    edges.reserve((size_t)n * 3);
+    for (uint32_t f = 0; f < n; ++f)
+        for (int e = 0; e < 3; ++e) edges[key_of(P + 9 * (size_t)f + 3 * e, P + 9 * (size_t)f + 3 * ((e + 1) % 3))].push_back(f);
+    std::vector<char> used(n, 0);
+    rotation.assign(n, 0);
+    for (uint32_t f = 0; f < n; ++f) {
+        if (used[f]) continue;
+        used[f] = 1;
+        uint32_t partner = Builder::kNone; int rot = 0;
+        for (int e = 0; e < 3 && partner == Builder::kNone; ++e) {
+            // edge (b, c) = vertices (e, e+1); a = vertex e+2
+            const float* b = P + 9 * (size_t)f + 3 * e; const float* c = P + 9 * (size_t)f + 3 * ((e + 1) % 3); const float* a = P + 9 * (size_t)f + 3 * ((e + 2) % 3);
+            auto it = edges.find(key_of(b, c));
+            if (it == edges.end()) continue;
+            for (uint32_t g : it->second) {
+                if (g == f || used[g] || (group && group[g] != group[f])) continue;
+                // the vertex of g that is neither b nor c
+                const float* d = nullptr;
+                for (int k = 0; k < 3; ++k) {
+                    const float* v = P + 9 * (size_t)g + 3 * k;
+                    if (std::memcmp(v, b, 12) && std::memcmp(v, c, 12)) d = v;
+                }
+                if (!d) continue;
+                bool ok = true;
+                for (int k = 0; k < 3; ++k) ok = ok && std::fabs(d[k] - (b[k] + c[k] - a[k])) <= tol;
+                if (!ok) continue;
+                partner = g; rot = (e + 2) % 3; // A is used with `a` as its first vertex
+                break;
+            }
+        }
+        primA.push_back(f); primB.push_back(partner); rotation[f] = rot;
+        if (partner != Builder::kNone) used[partner] = 1;
+    }
+}
+} // namespace
+
+BvhResult build_bvh(const float* P, const int32_t* group, uint32_t n, int max_depth)
 {
     BvhResult res;
-    if (const char* e = std::getenv("PTAMD_LEAF_MAX")) kLeafMax = (uint32_t)std::max(1, std::min(8, std::atoi(e)));
+    if (const char* e = std::getenv("PTAMD_LEAF_MAX")) kLeafMax = (uint32_t)std::max(1, std::min(4, std::atoi(e)));
     if (const char* e = std::getenv("PTAMD_COST_TRI")) kCostTri = (float)std::atof(e);
     Builder b;
     b.maxDepth = max_depth;
-    b.fb.resize(n); b.fc.resize(3 * (size_t)n); b.idx.resize(n);
     Box3 all; all.reset();
-    for (uint32_t i = 0; i < n; ++i) {
-        const float* p = P + 9 * (size_t)i;
-        Box3 t; t.reset();
-        t.grow(p); t.grow(p + 3); t.grow(p + 6);
-        b.fb[i] = t; all.grow(t);
-        for (int k = 0; k < 3; ++k) b.fc[3 * (size_t)i + k] = (p[k] + p[3 + k] + p[6 + k]) * (1.0f / 3.0f);
-        b.idx[i] = i;
-    }
+    for (uint32_t i = 0; i < n; ++i) { const float* p = P + 9 * (size_t)i; all.grow(p); all.grow(p + 3); all.grow(p + 6); }
     float scale = 0.f;
     for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(all.lo[k]), std::fabs(all.hi[k])));
+    const bool quads = !std::getenv("PTAMD_NO_QUADS");
+    if (quads) pair_quads(P, group, n, 2e-6f * std::max(scale, 1e-20f), b.primA, b.primB, res.rotation);
+    else { for (uint32_t i = 0; i < n; ++i) { b.primA.push_back(i); b.primB.push_back(Builder::kNone); } res.rotation.assign(n, 0); }
+    const uint32_t np = (uint32_t)b.primA.size();
+    b.fb.resize(np); b.fc.resize(3 * (size_t)np); b.idx.resize(np);
+    for (uint32_t i = 0; i < np; ++i) {
+        Box3 t; t.reset();
+        const float* p = P + 9 * (size_t)b.primA[i];
+        t.grow(p); t.grow(p + 3); t.grow(p + 6);
+        if (b.primB[i] != Builder::kNone) { const float* q = P + 9 * (size_t)b.primB[i]; t.grow(q); t.grow(q + 3); t.grow(q + 6); ++res.num_quads; }
+        b.fb[i] = t;
+        if (b.primB[i] == Builder::kNone) for (int k = 0; k < 3; ++k) b.fc[3 * (size_t)i + k] = (p[k] + p[3 + k] + p[6 + k]) * (1.0f / 3.0f);
+        else { // centre of the parallelogram = midpoint of the shared edge
+            const int r = res.rotation[b.primA[i]];
+            const float* vb = p + 3 * ((r + 1) % 3); const float* vc = p + 3 * ((r + 2) % 3);
+            for (int k = 0; k < 3; ++k) b.fc[3 * (size_t)i + k] = 0.5f * (vb[k] + vc[k]);
+        }
+        b.idx[i] = i;
+    }
     // Child boxes are padded so that the fused-multiply-add slab test of the kernels never culls a
     // triangle an exact (b - o) / d test would keep (its rounding error is ~1e-7 of the coordinates).
     b.pad = 2e-6f * std::max(scale, 1e-20f);
-    b.nodes.reserve(n);
+    b.nodes.reserve(np); b.slots.reserve(n);
     Box3 rootBounds;
-    res.root = n ? b.build(0, n, 0, rootBounds) : ~0;
+    res.root = np ? b.build(0, np, 0, rootBounds) : ~0;
     res.nodes = std::move(b.nodes);
-    res.order = std::move(b.idx);
+    res.order = std::move(b.slots);
     res.depth = b.depthSeen;
     return res;
 }

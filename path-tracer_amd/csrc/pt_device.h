@@ -51,8 +51,8 @@ struct Ray { f3 o, d; };
 struct Best {
     float t;       // world-space distance (PathTracer.cpp:43 closestT)
     int obj;       // object index, -1 = miss
-    int tri;       // mesh: triangle index relative to tri_base
-    float u, v;    // mesh: barycentrics
+    int tri;       // mesh: triangle slot relative to tri_base
+    float u, v;    // mesh: barycentrics in that triangle's own record
 };
 
 // Sphere::RayIntersect (Sphere.cpp:32-53): returns t or -1.
@@ -149,7 +149,7 @@ PT_DEV f3 xform_normal(const float* minv, f3 n)
 // rounding. The distance window of the caller (Mesh.cpp:104) is applied between t and the barycentrics, so a
 // wave whose candidates are all out of range skips the rest. INCLUSIVE: accept t == tHi.
 template <bool INCLUSIVE>
-PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float tHi, float& t, float& u, float& v)
+PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float tHi, bool quad, float& t, float& u, float& v)
 {
     float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     f3 n = mk3(q0.x, q0.y, q0.z);
@@ -161,11 +161,13 @@ PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float
     u = dot(mk3(q1.x, q1.y, q1.z), h) + q1.w;
     if (u < 0.0f || u > 1.0f) return false;
     v = dot(mk3(q2.x, q2.y, q2.z), h) + q2.w;
-    return !(v < 0.0f || u + v > 1.0f);
+    // a quad (two triangles forming a parallelogram, this record = the one at corner a) covers the whole unit square
+    return !(v < 0.0f || (quad ? v > 1.0f : u + v > 1.0f));
 }
 
 PT_DEV float4 sample_nearest(const DScene& sc, int img, float u, float v);
-// Alpha MASK cutout (Mesh.cpp:106-125): false when the texel is below the cutoff.
+// Alpha MASK cutout (Mesh.cpp:106-125): false when the texel is below the cutoff. u, v: barycentrics in the
+// triangle's own record.
 PT_DEV bool alpha_pass(const DScene& sc, const DMesh& me, int tri, float u, float v)
 {
     const float4* sh = sc.shade + ((size_t)me.tri_base + (size_t)tri) * 7;
@@ -175,13 +177,30 @@ PT_DEV bool alpha_pass(const DScene& sc, const DMesh& me, int tri, float u, floa
     if (g.alpha_mode != 1) return true;
     float alpha = g.base_color_factor[3];
     if (g.base_color_tex >= 0) {
-        const float4* s = sc.shade + ((size_t)me.tri_base + (size_t)tri) * 7;
-        float4 s4 = s[4], s5 = s[5];
+        float4 s4 = sh[4], s5 = sh[5];
         float w = 1.0f - u - v;
         float tu = w * s4.z + u * s5.x + v * s5.z, tv = w * s4.w + u * s5.y + v * s5.w;
         alpha *= sample_nearest(sc, g.base_color_tex, tu, tv).w;
     }
     return !(alpha < g.alpha_cutoff);
+}
+// Barycentrics of the point where the ray meets the plane of the record (no range checks).
+PT_DEV void tri_uv(const float4* __restrict__ tp, f3 o, f3 d, float& u, float& v)
+{
+    float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+    f3 n = mk3(q0.x, q0.y, q0.z);
+    float t = (q0.w - dot(n, o)) * frcp(dot(n, d));
+    f3 h = o + d * t;
+    u = dot(mk3(q1.x, q1.y, q1.z), h) + q1.w;
+    v = dot(mk3(q2.x, q2.y, q2.z), h) + q2.w;
+}
+// The triangle of a hit on primitive record `slot`: the record's own triangle, or for a quad hit beyond the diagonal the
+// next slot, whose barycentrics come from its own record.
+PT_DEV int hit_triangle(const float4* tris, int slot, bool quad, f3 o, f3 d, float& u, float& v)
+{
+    if (!(quad && u + v > 1.0f)) return slot;
+    tri_uv(tris + (size_t)(slot + 1) * 3, o, d, u, v);
+    return slot + 1;
 }
 
 // Where the traversal reads BVH nodes (4 float4 each) and hot triangles (3 float4 each) from: the global arrays of
@@ -244,15 +263,19 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
                 pop();
             }
         }
-        if (cur < 0) { // leaf
+        if (cur < 0) { // leaf: 1..4 primitives; ~ref = first_slot << 6 | quad_mask << 2 | (primitives - 1)
             uint32_t code = ~(uint32_t)cur;
-            uint32_t first = code >> 3, cnt_tris = (code & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt_tris; ++i) {
+            uint32_t slotIdx = code >> 6, mask = (code >> 2) & 15u, prims = (code & 3u) + 1u;
+            for (uint32_t i = 0; i < prims; ++i, mask >>= 1) {
                 if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
+                const bool quad = (mask & 1u) != 0u;
+                const uint32_t rec = slotIdx;
+                slotIdx += quad ? 2u : 1u;
                 float t, u, v;
-                if (!tri_test<false>(tris + (size_t)(first + i) * 3, o, d, tMinObj, closestT, t, u, v)) continue; // Mesh.cpp:104
-                if ((me.flags & 1u) && !alpha_pass(sc, me, (int)(first + i), u, v)) continue; // Mesh.cpp:106-125
-                closestT = t; bestTri = (int)(first + i); bu = u; bv = v;
+                if (!tri_test<false>(tris + (size_t)rec * 3, o, d, tMinObj, closestT, quad, t, u, v)) continue; // Mesh.cpp:104
+                const int tri = hit_triangle(tris, (int)rec, quad, o, d, u, v);
+                if ((me.flags & 1u) && !alpha_pass(sc, me, tri, u, v)) continue; // Mesh.cpp:106-125
+                closestT = t; bestTri = tri; bu = u; bv = v;
             }
             pop();
         }
@@ -381,14 +404,21 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
             }
         } else if (isLeaf) {
             uint32_t code = ~(uint32_t)cur;
-            uint32_t first = code >> 3, cnt_tris = (code & 7u) + 1u;
-            for (uint32_t i = 0; i < cnt_tris; ++i) {
+            uint32_t slotIdx = code >> 6, mask = (code >> 2) & 15u, prims = (code & 3u) + 1u;
+            for (uint32_t i = 0; i < prims; ++i, mask >>= 1) {
                 if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
+                const bool quad = (mask & 1u) != 0u;
+                const uint32_t rec = slotIdx;
+                slotIdx += quad ? 2u : 1u;
                 float t, u, v;
-                if (!tri_test<true>(tris + (size_t)(first + i) * 3, o, d, tMinObj, bound, t, u, v)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
-                if ((me.flags & 1u) && !alpha_pass(sc, me, (int)(first + i), u, v)) continue; // Mesh.cpp:106-125
+                if (!tri_test<true>(tris + (size_t)rec * 3, o, d, tMinObj, bound, quad, t, u, v)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
+                int tri = (int)rec + ((quad && u + v > 1.0f) ? 1 : 0);
+                if (me.flags & 1u) { // Mesh.cpp:106-125
+                    tri = hit_triangle(tris, (int)rec, quad, o, d, u, v);
+                    if (!alpha_pass(sc, me, tri, u, v)) continue;
+                }
                 bound = t;
-                atomicMin(&coop.res[waveBase + owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(first + i + 1u));
+                atomicMin(&coop.res[waveBase + owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((uint32_t)tri + 1u));
             }
             pop();
         }
@@ -431,10 +461,7 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
             if (COOP) {
                 tri = mesh_traverse_coop<BLOCK, COUNT>(sc, geom, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt);
                 if (!valid) tri = -1;
-                if (tri >= 0) { // barycentrics of the winner: its test repeated on this lane's own ray
-                    float tt;
-                    (void)tri_test<true>(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, oo, dd, 0.0f, 3.0e38f, tt, u, v);
-                }
+                if (tri >= 0) tri_uv(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, oo, dd, u, v); // the winner's own record, this lane's own ray
             } else {
                 mesh_traverse<BLOCK, COUNT>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt);
             }
@@ -527,7 +554,8 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
         float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
         f3 pa = mk3(s0.x, s0.y, s0.z), pb = mk3(s0.w, s1.x, s1.y), pc = mk3(s1.z, s1.w, s2.x);
         f3 na = mk3(s2.y, s2.z, s2.w), nb = mk3(s3.x, s3.y, s3.z), nc = mk3(s3.w, s4.x, s4.y);
-        float u = best.u, v = best.v, w = 1.0f - u - v;
+        float u = best.u, v = best.v;
+        float w = 1.0f - u - v;
         f3 pObj = (pa * w + pb * u) + pc * v;
         f3 nObj = normalize((na * w + nb * u) + nc * v);
         f3 nObjG = normalize(cross(pb - pa, pc - pa));

@@ -154,7 +154,7 @@ int copy_mesh_desc(const ptamd_mesh_desc* d, Model& m)
 {
     if (!d || !d->positions) return fail(PTAMD_ERR_ARG, "mesh description without positions");
     if (d->num_faces == 0) return fail(PTAMD_ERR_ARG, "Mesh: no faces in model"); // Mesh.cpp:293
-    if (d->num_faces >= (1u << 28)) return fail(PTAMD_ERR_LIMIT, "mesh has too many faces (limit 2^28 - 1)");
+    if (d->num_faces >= (1u << 25)) return fail(PTAMD_ERR_LIMIT, "mesh has too many faces (limit 2^25 - 1)");
     const size_t nf = d->num_faces;
     m.positions.assign(d->positions, d->positions + nf * 9);
     if (d->normals) m.normals.assign(d->normals, d->normals + nf * 9); else m.normals.assign(nf * 9, 0.0f);
@@ -327,7 +327,7 @@ int ptamd_scene_add_mesh_file(ptamd_scene* s, const char* path, const float pos[
         return fail(PTAMD_ERR_IO, e.what());
     }
     if (hm->model.num_faces() == 0) return fail(PTAMD_ERR_IO, "Mesh: no faces in model");
-    if (hm->model.num_faces() >= (1u << 28)) return fail(PTAMD_ERR_LIMIT, "mesh has too many faces (limit 2^28 - 1)");
+    if (hm->model.num_faces() >= (1u << 25)) return fail(PTAMD_ERR_LIMIT, "mesh has too many faces (limit 2^25 - 1)");
     return add_mesh_object(s, hm, pos, rot, scl);
 }
 int ptamd_scene_set_transform(ptamd_scene* s, int object, const float pos[3], const float rot[3], const float size[3])
@@ -426,7 +426,7 @@ int ptamd_scene_commit(ptamd_scene* s)
             HostMesh& hm = *ho.mesh;
             const Model& md = hm.model;
             if (!hm.bvh_valid) {
-                hm.bvh = build_bvh(md.positions.data(), md.num_faces(), maxDepth);
+                hm.bvh = build_bvh(md.positions.data(), md.group.data(), md.num_faces(), maxDepth);
                 hm.bvh_valid = true;
                 if (hm.bvh.depth > maxDepth) return fail(PTAMD_ERR_LIMIT, "BVH deeper than the traversal stack");
             }
@@ -459,7 +459,16 @@ int ptamd_scene_commit(ptamd_scene* s)
                 }
                 for (uint32_t i = 0; i < md.num_faces(); ++i) {
                     uint32_t f = hm.bvh.order[i];
-                    const float* p = &md.positions[9 * (size_t)f];
+                    // vertices in the order of the hot record: a quad's first triangle starts at the corner opposite the
+                    // shared edge (a cyclic rotation: same triangle, same orientation)
+                    const int rot = hm.bvh.rotation[f];
+                    float p[9], nrm[9], uv[6];
+                    for (int k = 0; k < 3; ++k) {
+                        const int src = (k + rot) % 3;
+                        std::memcpy(p + 3 * k, &md.positions[9 * (size_t)f + 3 * src], 12);
+                        std::memcpy(nrm + 3 * k, &md.normals[9 * (size_t)f + 3 * src], 12);
+                        std::memcpy(uv + 2 * k, &md.texcoords[6 * (size_t)f + 2 * src], 8);
+                    }
                     DTri t; std::memset(&t, 0, sizeof t);
                     {
                         const double v0[3] = { p[0], p[1], p[2] };
@@ -479,8 +488,8 @@ int ptamd_scene_commit(ptamd_scene* s)
                     tris.push_back(t);
                     DShade sh; std::memset(&sh, 0, sizeof sh);
                     std::memcpy(sh.pa, p, 36);
-                    std::memcpy(sh.na, &md.normals[9 * (size_t)f], 36);
-                    std::memcpy(sh.ta, &md.texcoords[6 * (size_t)f], 24);
+                    std::memcpy(sh.na, nrm, 36);
+                    std::memcpy(sh.ta, uv, 24);
                     sh.group = md.group[f];
                     sh.material = md.group[f] >= 0 ? faceMaterial[(size_t)md.group[f]] : 0;
                     shade.push_back(sh);

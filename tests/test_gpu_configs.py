@@ -125,3 +125,35 @@ def test_config2_full_size_properties(gpu, golden):
     gpu.Render(cam, pt, f2, 100, 8, spp_begin=0)
     gpu.Render(cam, pt, f2, spp - 100, 8, spp_begin=100)
     assert np.array_equal(f2.Accum()[::7].view(np.uint32), film.Accum()[::7].view(np.uint32))
+
+
+def test_quad_primitives_match_separate_triangles(gpu, monkeypatch):
+    """Two triangles that form a parallelogram are tested as one primitive. Switching the pairing off must give the
+    same closest hits (same t, point, normal, material) and the same per-sample radiance."""
+    scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 64)
+    pt, cam = gpu.build_scene(scene)
+    rays = cam.GetRays().reshape(-1, 6)
+    rng = np.random.default_rng(5)
+    o = (rng.random((20000, 3)) * 5.0 + 0.25).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([rays, np.concatenate([o, d], 1)])
+    a, ca = pt.TraversalCounts(rays)
+    film = gpu.Film(96, 64)
+    gpu.Render(cam, pt, film, 4, 6, seed=8)
+    fa = film.Accum()
+    monkeypatch.setenv("PTAMD_NO_QUADS", "1")
+    pt2, _ = gpu.build_scene(scene)
+    b, cb = pt2.TraversalCounts(rays)
+    film2 = gpu.Film(96, 64)
+    gpu.Render(cam, pt2, film2, 4, 6, seed=8)
+    fb = film2.Accum()
+    assert ca[:, 1].sum() < 0.85 * cb[:, 1].sum()  # fewer primitive tests: the pairing really happened
+    assert np.array_equal(a[:, 0], b[:, 0])
+    hit = a[:, 0] == 1
+    assert np.abs(a[hit, 1] - b[hit, 1]).max() <= 2e-6 * np.abs(b[hit, 1]).max()
+    assert np.abs(a[hit, 2:5] - b[hit, 2:5]).max() <= 2e-5
+    assert (np.abs(a[hit, 5:8] - b[hit, 5:8]).max(axis=1) <= 1e-5).mean() >= 0.999  # a ray through a shared edge may pick the neighbour
+    assert np.array_equal(a[hit, 9:], b[hit, 9:])
+    close = np.abs(fa - fb).max(axis=-1) <= 1e-4 + 1e-4 * np.abs(fb).max(axis=-1)
+    assert close.mean() >= 0.99, close.mean()
