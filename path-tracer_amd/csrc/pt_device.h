@@ -294,7 +294,7 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
 //     shared pruning bound that every task re-reads when it pops its stack.
 //   * the per-lane stack is used as a deque: its owner pops at the top, a thief takes the oldest entry (the
 //     largest pending subtree) at the bottom.
-//   * a steal round runs when at least kStealMin lanes are idle and some lane has pending entries: idle lane
+//   * a steal round runs when at least PT_STEAL_MIN lanes are idle and some lane has pending entries: idle lane
 //     number r pairs with pending lane number r through a small mailbox, copies that lane's ray with cross-lane
 //     reads and starts on the stolen subtree.
 // Every loop trip some lane advances (node step, leaf, or a steal that hands out a pending subtree), and the

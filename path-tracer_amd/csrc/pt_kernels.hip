@@ -2,9 +2,9 @@
 //
 // render_kernel: one lane per pixel, one wave per 8x8-pixel tile. Each lane runs every sample of its
 // pixel for this launch with *path regeneration*: the loop body is one ray segment (closest hit +
-// shade); a lane whose path ends adds the sample to its register accumulator and immediately starts
-// the next sample, so lanes stay busy although path lengths differ. The film is read once and
-// written once per launch (16 B per pixel), in the reference's sample order.
+// shade); a lane whose path ends adds the sample to its film sum and immediately starts the next
+// sample, so lanes stay busy although path lengths differ. The film is read once and written once
+// per launch (16 B per pixel each way), in the reference's sample order.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -43,11 +43,12 @@ PT_DEV void add_sample(f3& acc, f3 c)
     acc = acc + c;
 }
 
-// Dynamic LDS layout: [rp.stack_depth][kBlock] traversal stack entries (the depth of the scene's deepest tree), [kLaneFloats][kBlock] parked per-lane floats,
-// (LDS_GEOM) the staged nodes and triangles.
-// Occupancy: the bounce loop is latency bound (dependent VALU chains, LDS and L1 round trips), and its
-// throughput scales almost linearly with resident waves up to 5 per SIMD; asking for 5 holds the register
-// allocator to 96 VGPRs, which it meets without spilling. 6 (80 VGPRs) and 8 (64) spill into the loop and lose.
+// Dynamic LDS layout: [rp.stack_depth][kBlock] traversal stack entries (the depth of the scene's deepest tree),
+// [kLaneFloats][kBlock] per-lane floats, then either the staged nodes and triangles (LDS_GEOM) or the work-sharing
+// words of the cooperative traversal.
+// Occupancy: throughput grows with resident waves up to 5 per SIMD, where the vector ALU saturates; asking for 5
+// holds the register allocator to 96 VGPRs, which the LDS_GEOM builds meet without spilling. 6 (80 VGPRs) and
+// 8 (64) spill into the loop and lose.
 // COUNT: also tally rays, BVH node visits and triangle tests (PTAMD_FLAG_COUNT); kept out of the timed build.
 // EXT: the two options the reference does not have, Russian roulette and the cubemap sky; a build of its own so
 // that the default kernel carries neither their registers nor their branches.
@@ -57,7 +58,7 @@ constexpr int kNumCounters = 10;        // fields of ptamd_stats, in order
 #define PT_WAVES 5
 #endif
 #ifndef PT_WAVES_COOP
-#define PT_WAVES_COOP 4 // the cooperative traversal needs ~118 VGPRs; spilling them costs more than the fifth wave brings
+#define PT_WAVES_COOP 4 // the cooperative traversal needs ~112 VGPRs; spilling them costs more than the fifth wave brings
 #endif
 constexpr int kLaneFloats = 3;          // per-lane floats parked in LDS: the film sum of the lane's pixel
 template <bool LDS_GEOM, bool COUNT, bool EXT>
@@ -97,16 +98,11 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
         lds_acc[slot] = a0.x; lds_acc[kBlock + slot] = a0.y; lds_acc[2 * kBlock + slot] = a0.z;
     }
 
-    // Path state. (Parking throughput and radiance in LDS next to the film sum was measured: no gain.) The primary
-    // ray is recomputed for every sample (no jitter: Camera.cpp:47-48) instead of held.
-    f3 Treg, Lreg;
-    auto ldT = [&]() { return Treg; };
-    auto ldL = [&]() { return Lreg; };
-    auto stT = [&](f3 v) { Treg = v; };
-    auto stL = [&](f3 v) { Lreg = v; };
+    // Path state: throughput T, radiance L, medium index, bounce, random key. The primary ray is recomputed for
+    // every sample (no jitter: Camera.cpp:47-48) instead of held.
     Ray ray = camera_ray(rp.cam, px, py);
     float ior = 1.0f;
-    stT(mk3(1.f, 1.f, 1.f)); stL(mk3(0.f, 0.f, 0.f));
+    f3 T = mk3(1.f, 1.f, 1.f), L = mk3(0.f, 0.f, 0.f);
     int bounce = 0;
     uint32_t key = path_key(seed_hash, pixel, s);
     uint32_t nrays = 0;
@@ -125,8 +121,6 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
             best = closest_hit<kBlock, false, COOP>(sc, geom, ray, stack, coop, slot);
         }
         bool done;
-        f3 L = ldL();
-        const f3 T = ldT();
         if (best.obj < 0) {
             const f3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
             L = L + T * ((EXT && sc.sky_size > 0) ? sky_lookup(sc, ray.d) : bg); // PathTracer.cpp:59-60
@@ -146,14 +140,13 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
                 } else {
                     f3 w;
                     done = !sample_bsdf(h, ray, ior, w, key, (uint32_t)bounce);
-                    f3 Tn = T * w;
+                    T = T * w;
                     if (EXT && (rp.flags & kFlagRoulette) && bounce + 1 >= 3 && !done) {
                         // survive with probability q = clamp(max T, 0.05, 1), drawn from slot 7 of this bounce
-                        float q = clampf(fmaxf(fmaxf(Tn.x, Tn.y), Tn.z), 0.05f, 1.0f);
+                        float q = clampf(fmaxf(fmaxf(T.x, T.y), T.z), 0.05f, 1.0f);
                         if (!(rand01(key, (uint32_t)bounce, 7u) < q)) done = true;
-                        else Tn = Tn * __fdiv_rn(1.0f, q);
+                        else T = T * __fdiv_rn(1.0f, q);
                     }
-                    stT(Tn);
                     ++bounce;
                 }
             }
@@ -164,11 +157,10 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
             lds_acc[slot] = acc.x; lds_acc[kBlock + slot] = acc.y; lds_acc[2 * kBlock + slot] = acc.z;
             ++s;
             ray = camera_ray(rp.cam, px, py); ior = 1.0f;
-            stT(mk3(1.f, 1.f, 1.f)); L = mk3(0.f, 0.f, 0.f);
+            T = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f);
             bounce = 0;
             key = path_key(seed_hash, pixel, s);
         }
-        stL(L);
     }
 
     if (inside) {
