@@ -181,6 +181,10 @@ def main():
                                        "(32 B/pixel/launch) traffic is negligible; `achieved` prices the reference "
                                        "algorithm's counted slab/triangle/box tests and shades on this scene (CPU oracle "
                                        "counters), `executed` the tests this kernel's own BVH walk performed"}
+            traffic = out["roofline"]["traffic"]
+            if traffic is not None:  # the HBM view of the same launch, to show why the bound is not "hbm"
+                out["roofline"]["hbm"] = {"achieved": traffic / (kernel_ms * 1e-3) * 1e-9, "peak": 8000.0, "unit": "GB/s",
+                                          "frac": traffic / (kernel_ms * 1e-3) * 1e-9 / 8000.0}
             out["cpu_baseline"] = base
             out["speedup_vs_cpu_baseline"] = value / base["value"]
         print(json.dumps(out), flush=True)
