@@ -109,7 +109,9 @@ typedef struct ptamd_model ptamd_model;
 /* ---- context ------------------------------------------------------------------------------ */
 /* Selects the HIP device for this process and creates the library's stream.  No reference
  * counterpart (the reference is CPU-only).  Fails with PTAMD_ERR_DEVICE when no GPU is usable:
- * there is no CPU fallback. */
+ * there is no CPU fallback.  One process drives one GPU: a second call must name the same device.
+ * The library keeps process-wide state (device, stream, counters); calls that touch the same scene or
+ * film handle, or that change the stream, must not overlap (the last-error string is per thread). */
 int ptamd_init(int device);
 /* Use a caller-owned hipStream_t (e.g. PyTorch's current stream) for all later launches, copies and memsets.
  * NULL is HIP's default (null) stream. ptamd_reset_stream goes back to the library's own non-blocking stream. */

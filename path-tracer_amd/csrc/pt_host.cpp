@@ -33,6 +33,7 @@ thread_local std::string g_error;
 hipStream_t g_own_stream = nullptr;
 hipStream_t g_stream = nullptr;
 bool g_initialised = false;
+int g_device = -1;
 constexpr int kNumCounters = 10;
 unsigned long long* g_counters = nullptr; // device, kNumCounters x u64 (the fields of ptamd_stats)
 
@@ -155,6 +156,8 @@ int copy_mesh_desc(const ptamd_mesh_desc* d, Model& m)
     if (!d || !d->positions) return fail(PTAMD_ERR_ARG, "mesh description without positions");
     if (d->num_faces == 0) return fail(PTAMD_ERR_ARG, "Mesh: no faces in model"); // Mesh.cpp:293
     if (d->num_faces >= (1u << 25)) return fail(PTAMD_ERR_LIMIT, "mesh has too many faces (limit 2^25 - 1)");
+    if (d->num_groups && !d->groups) return fail(PTAMD_ERR_ARG, "mesh description counts material groups but has no group array");
+    if (d->num_images && !d->images) return fail(PTAMD_ERR_ARG, "mesh description counts images but has no image array");
     const size_t nf = d->num_faces;
     m.positions.assign(d->positions, d->positions + nf * 9);
     if (d->normals) m.normals.assign(d->normals, d->normals + nf * 9); else m.normals.assign(nf * 9, 0.0f);
@@ -232,10 +235,11 @@ int ptamd_init(int device)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(PTAMD_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(PTAMD_ERR_ARG, "device index out of range");
+    if (g_initialised && device != g_device) return fail(PTAMD_ERR_STATE, "already initialised on another device (one process drives one GPU)");
     PT_HIP(hipSetDevice(device));
     if (!g_own_stream) { PT_HIP(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking)); g_stream = g_own_stream; }
     if (!g_counters) PT_HIP(hipMalloc(reinterpret_cast<void**>(&g_counters), kNumCounters * sizeof(unsigned long long)));
-    g_initialised = true;
+    g_initialised = true; g_device = device;
     return PTAMD_OK;
 }
 int ptamd_set_stream(void* s)
@@ -389,7 +393,11 @@ int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const f
     const size_t n = (size_t)face_size * face_size;
     std::vector<uint32_t> tex(6 * n);
     for (int f = 0; f < 6; ++f) std::memcpy(tex.data() + f * n, faces[f], n * 4);
-    if (int rc = s->d_sky.upload(tex)) return rc;
+    if (int rc = s->d_sky.upload(tex)) { // the old map is gone and the new one did not arrive: fall back to the constant background
+        s->d_sky.release(); s->sky_size = 0;
+        s->dscene.sky = nullptr; s->dscene.sky_size = 0;
+        return rc;
+    }
     s->sky_size = face_size; s->sky_intensity = intensity;
     s->dscene.sky = s->d_sky.ptr; s->dscene.sky_size = face_size; s->dscene.sky_intensity = intensity;
     return PTAMD_OK;

@@ -158,3 +158,23 @@ def test_gltf_rejects_what_the_reference_rejects(tmp_path):
         h = C.c_void_p()
         assert L.ptamd_model_load(str(p).encode(), C.byref(h)) == -2
         assert msg in L.ptamd_last_error(), L.ptamd_last_error()
+
+
+def test_mesh_description_is_validated():
+    """Null arrays behind non-zero counts are refused instead of dereferenced."""
+    L = ptamd.lib()
+    h = C.c_void_p()
+    assert L.ptamd_scene_create(C.byref(h)) == 0
+    d = ptamd.CMeshDesc()
+    P = (C.c_float * 9)(0, 0, 0, 1, 0, 0, 0, 1, 0)
+    d.num_faces = 1
+    d.positions = C.cast(P, C.c_void_p)
+    f3 = lambda *v: (C.c_float * 3)(*v)
+    d.num_groups = 2
+    assert L.ptamd_scene_add_mesh(h, C.byref(d), f3(0, 0, 0), f3(0, 0, 0), f3(1, 1, 1)) == -1 and b"no group array" in L.ptamd_last_error()
+    d.num_groups = 0
+    d.num_images = 1
+    assert L.ptamd_scene_add_mesh(h, C.byref(d), f3(0, 0, 0), f3(0, 0, 0), f3(1, 1, 1)) == -1 and b"no image array" in L.ptamd_last_error()
+    d.num_images = 0
+    assert L.ptamd_scene_add_mesh(h, C.byref(d), f3(0, 0, 0), f3(0, 0, 0), f3(1, 1, 1)) == 0
+    assert L.ptamd_scene_destroy(h) == 0
