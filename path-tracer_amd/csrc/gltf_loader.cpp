@@ -282,7 +282,21 @@ int texture_source(const Doc& d, const JValue* texInfo)
 
 } // namespace
 
+static void load_any(const std::string& path, Model& out, uint32_t flags);
+
+// Every index the kernels will follow is checked here once: a file whose material points at an image or whose face
+// points at a group that does not exist is refused instead of read out of bounds on the device.
 void load_gltf(const std::string& path, Model& out, uint32_t flags)
+{
+    load_any(path, out, flags);
+    for (const ptamd_pbr& g : out.groups) {
+        const int32_t tex[5] = { g.base_color_tex, g.normal_tex, g.metallic_roughness_tex, g.emissive_tex, g.transmission_tex };
+        for (int32_t t : tex) if (t >= (int32_t)out.images.size()) throw std::runtime_error("model material refers to an image that the file does not hold: " + path);
+    }
+    for (int32_t g : out.group) if (g >= (int32_t)out.groups.size()) throw std::runtime_error("model face refers to a missing material group: " + path);
+}
+
+static void load_any(const std::string& path, Model& out, uint32_t flags)
 {
     // ModelLoader.h:129-142
     std::string ext;

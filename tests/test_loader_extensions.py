@@ -100,3 +100,23 @@ def test_load_flags_are_validated():
     import ctypes as C
     h = C.c_void_p()
     assert L.ptamd_model_load_ex(b"x.glb", 8, C.byref(h)) == -1 and b"unknown load flag" in L.ptamd_last_error()
+
+
+def test_material_pointing_at_a_missing_image_is_refused(tmp_path):
+    prim = gltf_io.box_primitive((0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    mat = gltf_io.gltf_material("m", [0.8, 0.2, 0.2, 0.5, 0.0, 1, 1, 1, 0.0, 1.5, 0.0])
+    mat["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0}
+    path = str(tmp_path / "bad.gltf")
+    # a texture whose source image index is past the (empty) image list
+    import json, struct
+    gltf_io.write_glb(str(tmp_path / "ok.glb"), [prim], [mat])
+    raw = open(tmp_path / "ok.glb", "rb").read()
+    n = struct.unpack_from("<I", raw, 12)[0]
+    doc = json.loads(raw[20:20 + n])
+    blob = raw[20 + n + 8:]
+    doc["textures"] = [{"source": 3}]
+    import base64
+    doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+    open(path, "w").write(json.dumps(doc))
+    with pytest.raises(ptamd.PtamdError, match="image that the file does not hold"):
+        ptamd.load_model(path)
