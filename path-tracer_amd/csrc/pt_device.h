@@ -224,34 +224,34 @@ template <int BLOCK, bool COUNT>
 PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f3 o, f3 d, float tMinObj, float& closestT,
                           int& bestTri, float& bu, float& bv, StackEntry* __restrict__ stack, int slot, TraversalCounts& cnt)
 {
-    const float4* __restrict__ nodes = geom.nodes + (size_t)me.node_base * 4;
+    const char* __restrict__ nodes = reinterpret_cast<const char*>(geom.nodes) + (size_t)me.node_base * kLdsNodeBytes;
     const float4* __restrict__ tris = geom.tris + (size_t)me.tri_base * 3;
     const float BIG = 1e30f;
     f3 inv = mk3(fabsf(d.x) > 1e-30f ? frcp(d.x) : BIG, fabsf(d.y) > 1e-30f ? frcp(d.y) : BIG, fabsf(d.z) > 1e-30f ? frcp(d.z) : BIG);
     f3 oi = o * inv;
-    constexpr int kDone = 0x7fffffff; // never a valid node index
+    // where this ray reads each axis of a node from: the four floats that start with the planes it enters through
+    const char* __restrict__ ax = nodes + (inv.x < 0.0f ? 16 : 0);
+    const char* __restrict__ ay = nodes + 32 + (inv.y < 0.0f ? 16 : 0);
+    const char* __restrict__ az = nodes + 64 + (inv.z < 0.0f ? 16 : 0);
+    constexpr int kDone = 0x7fffffff; // never a valid node reference
     int sp = 0;
-    int cur = me.root;
+    int cur = me.root >= 0 ? me.root * (int)kLdsNodeBytes : me.root; // inner nodes: byte offset
     auto pop = [&]() {
         if (sp > 0) { --sp; cur = (int)stack[sp * BLOCK + slot]; } else cur = kDone;
     };
     while (cur != kDone) {
         while ((uint32_t)cur < (uint32_t)kDone) { // inner node
             if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
-            const float4* n = nodes + (size_t)cur * 4;
-            float4 a = n[0], b = n[1], c = n[2], r = n[3];
-            float lx0 = fmaf(a.x, inv.x, -oi.x), lx1 = fmaf(a.w, inv.x, -oi.x);
-            float ly0 = fmaf(a.y, inv.y, -oi.y), ly1 = fmaf(b.x, inv.y, -oi.y);
-            float lz0 = fmaf(a.z, inv.z, -oi.z), lz1 = fmaf(b.y, inv.z, -oi.z);
-            float rx0 = fmaf(b.z, inv.x, -oi.x), rx1 = fmaf(c.y, inv.x, -oi.x);
-            float ry0 = fmaf(b.w, inv.y, -oi.y), ry1 = fmaf(c.z, inv.y, -oi.y);
-            float rz0 = fmaf(c.x, inv.z, -oi.z), rz1 = fmaf(c.w, inv.z, -oi.z);
-            float lmin = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), 0.0f));
-            float lmax = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), closestT));
-            float rmin = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), 0.0f));
-            float rmax = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), closestT));
+            const float4 x = *reinterpret_cast<const float4*>(ax + cur); // l.near, r.near, l.far, r.far
+            const float4 y = *reinterpret_cast<const float4*>(ay + cur);
+            const float4 z = *reinterpret_cast<const float4*>(az + cur);
+            const int2 ch = *reinterpret_cast<const int2*>(nodes + cur + 96);
+            float lmin = fmaxf(fmaxf(fmaf(x.x, inv.x, -oi.x), fmaf(y.x, inv.y, -oi.y)), fmaxf(fmaf(z.x, inv.z, -oi.z), 0.0f));
+            float lmax = fminf(fminf(fmaf(x.z, inv.x, -oi.x), fmaf(y.z, inv.y, -oi.y)), fminf(fmaf(z.z, inv.z, -oi.z), closestT));
+            float rmin = fmaxf(fmaxf(fmaf(x.y, inv.x, -oi.x), fmaf(y.y, inv.y, -oi.y)), fmaxf(fmaf(z.y, inv.z, -oi.z), 0.0f));
+            float rmax = fminf(fminf(fmaf(x.w, inv.x, -oi.x), fmaf(y.w, inv.y, -oi.y)), fminf(fmaf(z.w, inv.z, -oi.z), closestT));
             bool hl = lmax >= lmin, hr = rmax >= rmin;
-            int left = __float_as_int(r.x), right = __float_as_int(r.y);
+            const int left = ch.x, right = ch.y;
             if (hl && hr) {
                 bool leftNear = lmin < rmin; // Mesh.cpp:143
                 stack[sp * BLOCK + slot] = (uint32_t)(leftNear ? right : left);

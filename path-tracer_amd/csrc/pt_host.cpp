@@ -86,13 +86,13 @@ struct ptamd_scene {
     float background[3] = { 0.2f, 0.2f, 0.2f };
     bool committed = false;
     DevBuf<DObject> d_objects; DevBuf<DMesh> d_meshes; DevBuf<DMaterial> d_materials;
-    DevBuf<DNode> d_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
+    DevBuf<DNode> d_nodes; DevBuf<float> d_lds_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
     DevBuf<uint32_t> d_sky; int sky_size = 0; float sky_intensity = 1.0f;
     DScene dscene;
     void release() // what commit rebuilds; the sky map is uploaded by its own call and outlives commits
     {
-        d_objects.release(); d_meshes.release(); d_materials.release(); d_nodes.release(); d_tris.release();
+        d_objects.release(); d_meshes.release(); d_materials.release(); d_nodes.release(); d_lds_nodes.release(); d_tris.release();
         d_shade.release(); d_groups.release(); d_images.release(); d_texels.release();
     }
 };
@@ -403,6 +403,24 @@ int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const f
     return PTAMD_OK;
 }
 
+
+// ------------------------------------------------------------------------------- LDS nodes
+// Appends one LDS-format node (see kLdsNodeBytes in pt_types.h) per DNode.
+static void append_lds_nodes(const std::vector<DNode>& nodes, std::vector<float>& out)
+{
+    for (const DNode& n : nodes) {
+        const float lmin[3] = { n.lmin[0], n.lmin[1], n.lmin[2] }, lmax[3] = { n.lmax0, n.lmax12[0], n.lmax12[1] };
+        const float rmin[3] = { n.rmin01[0], n.rmin01[1], n.rmin2 }, rmax[3] = { n.rmax[0], n.rmax[1], n.rmax[2] };
+        for (int k = 0; k < 3; ++k) {
+            const float fwd[4] = { lmin[k], rmin[k], lmax[k], rmax[k] }, back[4] = { lmax[k], rmax[k], lmin[k], rmin[k] };
+            out.insert(out.end(), fwd, fwd + 4);
+            out.insert(out.end(), back, back + 4);
+        }
+        auto ref = [](int32_t r) { int32_t v = r >= 0 ? r * (int32_t)kLdsNodeBytes : r; float f; std::memcpy(&f, &v, 4); return f; };
+        out.push_back(ref(n.left)); out.push_back(ref(n.right)); out.push_back(0.0f); out.push_back(0.0f);
+    }
+}
+
 int ptamd_scene_commit(ptamd_scene* s)
 {
     if (int rc = check_scene(s)) return rc;
@@ -415,6 +433,8 @@ int ptamd_scene_commit(ptamd_scene* s)
     materials.push_back(to_dmaterial(defMat)); // slot 0: Material{} (faces without a material group, Mesh.cpp:242-246)
     std::vector<std::pair<const HostMesh*, uint32_t>> uploaded; // geometry shared by several instances is stored once
     struct MeshSlots { uint32_t node_base, tri_base, group_base, image_base; uint32_t flags; };
+    std::vector<float> ldsNodes; // LDS-format nodes of all meshes while they can still fit, kLdsNodeBytes each
+    bool ldsNodesOk = true;
     std::vector<MeshSlots> slots;
 
     for (const HostObject& ho : s->objects) {
@@ -445,6 +465,8 @@ int ptamd_scene_commit(ptamd_scene* s)
                 ms.node_base = (uint32_t)nodes.size(); ms.tri_base = (uint32_t)tris.size();
                 ms.group_base = (uint32_t)groups.size(); ms.image_base = (uint32_t)images.size(); ms.flags = 0;
                 nodes.insert(nodes.end(), hm.bvh.nodes.begin(), hm.bvh.nodes.end());
+                if (ldsNodesOk && (ldsNodes.size() * 4 + hm.bvh.nodes.size() * kLdsNodeBytes <= kLdsGeomBytes)) append_lds_nodes(hm.bvh.nodes, ldsNodes);
+                else ldsNodesOk = false;
                 std::vector<int32_t> faceMaterial; // per group: constant material slot, or -1 when the group samples images
                 for (const ptamd_pbr& g : md.groups) {
                     DPbr dg; std::memset(&dg, 0, sizeof dg);
@@ -530,6 +552,9 @@ int ptamd_scene_commit(ptamd_scene* s)
     if (int rc = s->d_meshes.upload(meshes)) return rc;
     if (int rc = s->d_materials.upload(materials)) return rc;
     if (int rc = s->d_nodes.upload(nodes)) return rc;
+    // small scenes are traversed from an LDS copy of their nodes (in LDS format) and hot triangles
+    const bool ldsResident = ldsNodesOk && !tris.empty() && ldsNodes.size() * 4 + tris.size() * sizeof(DTri) <= kLdsGeomBytes;
+    if (ldsResident && !ldsNodes.empty()) { if (int rc = s->d_lds_nodes.upload(ldsNodes)) return rc; }
     if (int rc = s->d_tris.upload(tris)) return rc;
     if (int rc = s->d_shade.upload(shade)) return rc;
     if (int rc = s->d_groups.upload(groups)) return rc;
@@ -540,6 +565,8 @@ int ptamd_scene_commit(ptamd_scene* s)
     ds.meshes = s->d_meshes.ptr; ds.materials = s->d_materials.ptr;
     ds.nodes = reinterpret_cast<const float4*>(s->d_nodes.ptr);
     ds.tris = reinterpret_cast<const float4*>(s->d_tris.ptr);
+    ds.lds_resident = ldsResident ? 1u : 0u;
+    ds.lds_nodes = ldsResident ? reinterpret_cast<const float4*>(s->d_lds_nodes.ptr) : nullptr; ds.lds_node_f4 = ldsResident ? (uint32_t)(ldsNodes.size() / 4) : 0u;
     ds.shade = reinterpret_cast<const float4*>(s->d_shade.ptr);
     ds.groups = s->d_groups.ptr; ds.images = s->d_images.ptr; ds.texels = s->d_texels.ptr;
     std::memcpy(ds.background, s->background, 12);

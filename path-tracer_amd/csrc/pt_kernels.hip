@@ -14,7 +14,6 @@ namespace ptamd {
 
 constexpr int kBlock = 256;      // 4 waves, each owning one 8x8 tile
 constexpr int kStackDepth = 32;  // deepest BVH (inner levels) the kernels can traverse: per-lane stack entries in LDS
-constexpr int kLdsGeomF4 = 1536; // up to 24 KB of BVH nodes + hot triangles of a small scene are staged into LDS
 
 // Copies the scene's nodes and hot triangles into LDS (when they fit) and returns where traversal reads them.
 template <bool LDS_GEOM>
@@ -22,10 +21,10 @@ PT_DEV Geom stage_geometry(const DScene& sc, float4* lds_geom)
 {
     Geom g;
     if (LDS_GEOM) {
-        // records stay contiguous (64-byte nodes, 48-byte triangles): the four 16-byte reads of a node then differ
-        // only in their immediate offset, which measured faster than a bank-spreading column-major copy
-        const uint32_t n4 = sc.num_nodes * 4u, t4 = sc.num_tris * 3u;
-        for (uint32_t i = threadIdx.x; i < n4; i += kBlock) lds_geom[i] = sc.nodes[i];
+        // the host's LDS-format nodes (see kLdsNodeBytes) and the hot triangles, records contiguous: the reads of one
+        // record then differ only in their immediate offset
+        const uint32_t n4 = sc.lds_node_f4, t4 = sc.num_tris * 3u;
+        for (uint32_t i = threadIdx.x; i < n4; i += kBlock) lds_geom[i] = sc.lds_nodes[i];
         for (uint32_t i = threadIdx.x; i < t4; i += kBlock) lds_geom[n4 + i] = sc.tris[i];
         __syncthreads();
         g.nodes = lds_geom; g.tris = lds_geom + n4;
@@ -262,9 +261,9 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     int tiles = rp.tiles_x * rp.tiles_y;
     int blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks <= 0) return hipSuccess;
-    const uint32_t geomF4 = sc.num_nodes * 4u + sc.num_tris * 3u;
-    const bool fits = geomF4 <= (uint32_t)kLdsGeomF4;
-    const size_t geomBytes = fits ? (size_t)geomF4 * 16 : 0;
+    const bool fits = sc.lds_resident != 0; // the host built LDS-format nodes: the scene fits kLdsGeomBytes
+    const size_t geomBytes = fits ? (size_t)(sc.lds_node_f4 + sc.num_tris * 3u) * 16 : 0;
+    if (geomBytes > kLdsGeomBytes) return hipErrorInvalidValue;
     DRenderParams p = rp;
     p.stack_depth = sc.max_stack < 1 ? 1 : (sc.max_stack > kStackDepth ? kStackDepth : sc.max_stack);
     const size_t lds = ((size_t)p.stack_depth * sizeof(StackEntry) + 4 * kLaneFloats + (fits ? 0 : 12)) * kBlock + geomBytes;

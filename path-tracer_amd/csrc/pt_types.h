@@ -55,6 +55,16 @@ struct DNode {
     int32_t left, right; int32_t pad[2]; // f4 3
 };
 
+// Node of the LDS-resident traversal (scenes whose nodes and hot triangles fit kLdsGeomBytes), built by the host
+// next to the DNode array, one per DNode in the same order, 28 dwords. Per axis eight floats
+// [l.min, r.min, l.max, r.max | l.max, r.max, l.min, r.min] (l, r: the two children's boxes): a ray that travels
+// along +axis reads the first four with one 16-byte read, one that travels along -axis the second four, and either
+// way gets (l.near, r.near, l.far, r.far) in its own order, so the slab test needs no per-axis min/max and computes
+// the same values (a * inv - o * inv is monotonic in a). Dwords 24, 25: child references, inner ones as byte
+// offsets from the mesh's first node, leaves as in DNode; 26, 27 pad.
+constexpr uint32_t kLdsNodeBytes = 112;
+constexpr uint32_t kLdsGeomBytes = 24576; // LDS nodes + hot triangles of a scene that is traversed from LDS
+
 // Hot triangle in plane form. With n = e1 x e2 (e1 = v1 - v0, e2 = v2 - v0): the determinant of Mesh::RayTriMT
 // (Mesh.cpp:421-431) is -(n . d), its t is (n . v0 - n . o) / (n . d), and the barycentrics of the hit point h
 // are u = m1 . h + d1, v = m2 . h + d2 with m1 = (e2 x n) / |n|^2, m2 = (n x e1) / |n|^2, d1 = -m1 . v0,
@@ -101,7 +111,10 @@ struct DScene {
     const DImage* images;
     const uint8_t* texels;
     float background[3]; int32_t pad;
-    uint32_t num_nodes, num_tris; // totals over all meshes (what an LDS-staged copy holds)
+    uint32_t num_nodes, num_tris; // totals over all meshes
+    const float4* lds_nodes;  // kLdsNodeBytes per node; present when lds_resident
+    uint32_t lds_node_f4;     // their size in float4
+    uint32_t lds_resident;    // the LDS nodes and the hot triangles fit kLdsGeomBytes: traverse them from LDS
     int32_t sky_size; float sky_intensity; // cubemap miss radiance (no reference counterpart): 0 = constant background
     const uint32_t* sky;   // 6 faces (+x -x +y -y +z -z) of sky_size^2 RGBA8 texels, row 0 = top
 };
