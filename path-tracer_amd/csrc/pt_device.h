@@ -272,7 +272,8 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
                 const uint32_t rec = slotIdx;
                 slotIdx += quad ? 2u : 1u;
                 float t, u, v;
-                if (!tri_test<false>(tris + (size_t)rec * 3, o, d, tMinObj, closestT, quad, t, u, v)) continue; // Mesh.cpp:104
+                // (records staged in LDS: their index fits 24 bits, and a 24-bit multiply runs at the full rate)
+                if (!tri_test<false>(tris + __umul24(rec, 3u), o, d, tMinObj, closestT, quad, t, u, v)) continue; // Mesh.cpp:104
                 const int tri = hit_triangle(tris, (int)rec, quad, o, d, u, v);
                 if ((me.flags & 1u) && !alpha_pass(sc, me, tri, u, v)) continue; // Mesh.cpp:106-125
                 closestT = t; bestTri = tri; bu = u; bv = v;

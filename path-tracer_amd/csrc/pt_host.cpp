@@ -553,7 +553,7 @@ int ptamd_scene_commit(ptamd_scene* s)
     if (int rc = s->d_materials.upload(materials)) return rc;
     if (int rc = s->d_nodes.upload(nodes)) return rc;
     // small scenes are traversed from an LDS copy of their nodes (in LDS format) and hot triangles
-    const bool ldsResident = ldsNodesOk && !tris.empty() && ldsNodes.size() * 4 + tris.size() * sizeof(DTri) <= kLdsGeomBytes;
+    const bool ldsResident = ldsNodesOk && ldsNodes.size() * 4 + tris.size() * sizeof(DTri) <= kLdsGeomBytes; // scenes without meshes included
     if (ldsResident && !ldsNodes.empty()) { if (int rc = s->d_lds_nodes.upload(ldsNodes)) return rc; }
     if (int rc = s->d_tris.upload(tris)) return rc;
     if (int rc = s->d_shade.upload(shade)) return rc;
