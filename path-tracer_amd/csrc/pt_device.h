@@ -51,7 +51,7 @@ struct Ray { f3 o, d; };
 struct Best {
     float t;       // world-space distance (PathTracer.cpp:43 closestT)
     int obj;       // object index, -1 = miss
-    int tri;       // mesh: triangle slot relative to tri_base
+    int tri;       // mesh: triangle slot relative to tri_base, | kFrontBit when the ray meets its front side
     float u, v;    // mesh: barycentrics in that triangle's own record
 };
 
@@ -149,11 +149,11 @@ PT_DEV f3 xform_normal(const float* minv, f3 n)
 // rounding. The distance window of the caller (Mesh.cpp:104) is applied between t and the barycentrics, so a
 // wave whose candidates are all out of range skips the rest. INCLUSIVE: accept t == tHi.
 template <bool INCLUSIVE>
-PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float tHi, bool quad, float& t, float& u, float& v)
+PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float tHi, bool quad, float& t, float& u, float& v, float& dn)
 {
     float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     f3 n = mk3(q0.x, q0.y, q0.z);
-    float dn = dot(n, d);
+    dn = dot(n, d);
     if (fabsf(dn) < 1e-8f) return false;
     t = (q0.w - dot(n, o)) * frcp(dn);
     if (!(t > 1e-8f) || t < tLo || (INCLUSIVE ? t > tHi : t >= tHi)) return false;
@@ -184,22 +184,29 @@ PT_DEV bool alpha_pass(const DScene& sc, const DMesh& me, int tri, float u, floa
     }
     return !(alpha < g.alpha_cutoff);
 }
-// Barycentrics of the point where the ray meets the plane of the record (no range checks).
-PT_DEV void tri_uv(const float4* __restrict__ tp, f3 o, f3 d, float& u, float& v)
+// Barycentrics of the point where the ray meets the plane of the record (no range checks); dn = n . d of that record.
+PT_DEV void tri_uv(const float4* __restrict__ tp, f3 o, f3 d, float& u, float& v, float& dn)
 {
     float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     f3 n = mk3(q0.x, q0.y, q0.z);
-    float t = (q0.w - dot(n, o)) * frcp(dot(n, d));
+    dn = dot(n, d);
+    float t = (q0.w - dot(n, o)) * frcp(dn);
     f3 h = o + d * t;
     u = dot(mk3(q1.x, q1.y, q1.z), h) + q1.w;
     v = dot(mk3(q2.x, q2.y, q2.z), h) + q2.w;
 }
+// The side of a triangle that a ray meets travels with the triangle index (bit 30; a mesh has fewer than 2^25
+// faces): Mesh.cpp:160-162,230-233 take it from the sign of direction . MinvT * normalize(e1 x e2), which is the
+// sign of n . d that the triangle test has just computed in object space (positive scale factors apart).
+constexpr int kFrontBit = 1 << 30;
+PT_DEV int with_side(int tri, float dn) { return dn < 0.0f ? (tri | kFrontBit) : tri; }
+
 // The triangle of a hit on primitive record `slot`: the record's own triangle, or for a quad hit beyond the diagonal the
-// next slot, whose barycentrics come from its own record.
-PT_DEV int hit_triangle(const float4* tris, int slot, bool quad, f3 o, f3 d, float& u, float& v)
+// next slot, whose barycentrics (and side) come from its own record.
+PT_DEV int hit_triangle(const float4* tris, int slot, bool quad, f3 o, f3 d, float& u, float& v, float& dn)
 {
     if (!(quad && u + v > 1.0f)) return slot;
-    tri_uv(tris + (size_t)(slot + 1) * 3, o, d, u, v);
+    tri_uv(tris + (size_t)(slot + 1) * 3, o, d, u, v, dn);
     return slot + 1;
 }
 
@@ -271,12 +278,12 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
                 const bool quad = (mask & 1u) != 0u;
                 const uint32_t rec = slotIdx;
                 slotIdx += quad ? 2u : 1u;
-                float t, u, v;
+                float t, u, v, dn;
                 // (records staged in LDS: their index fits 24 bits, and a 24-bit multiply runs at the full rate)
-                if (!tri_test<false>(tris + __umul24(rec, 3u), o, d, tMinObj, closestT, quad, t, u, v)) continue; // Mesh.cpp:104
-                const int tri = hit_triangle(tris, (int)rec, quad, o, d, u, v);
+                if (!tri_test<false>(tris + __umul24(rec, 3u), o, d, tMinObj, closestT, quad, t, u, v, dn)) continue; // Mesh.cpp:104
+                const int tri = hit_triangle(tris, (int)rec, quad, o, d, u, v, dn);
                 if ((me.flags & 1u) && !alpha_pass(sc, me, tri, u, v)) continue; // Mesh.cpp:106-125
-                closestT = t; bestTri = tri; bu = u; bv = v;
+                closestT = t; bestTri = with_side(tri, dn); bu = u; bv = v;
             }
             pop();
         }
@@ -411,11 +418,11 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
                 const bool quad = (mask & 1u) != 0u;
                 const uint32_t rec = slotIdx;
                 slotIdx += quad ? 2u : 1u;
-                float t, u, v;
-                if (!tri_test<true>(tris + (size_t)rec * 3, o, d, tMinObj, bound, quad, t, u, v)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
+                float t, u, v, dn;
+                if (!tri_test<true>(tris + (size_t)rec * 3, o, d, tMinObj, bound, quad, t, u, v, dn)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
                 int tri = (int)rec + ((quad && u + v > 1.0f) ? 1 : 0);
                 if (me.flags & 1u) { // Mesh.cpp:106-125
-                    tri = hit_triangle(tris, (int)rec, quad, o, d, u, v);
+                    tri = hit_triangle(tris, (int)rec, quad, o, d, u, v, dn);
                     if (!alpha_pass(sc, me, tri, u, v)) continue;
                 }
                 bound = t;
@@ -462,7 +469,11 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
             if (COOP) {
                 tri = mesh_traverse_coop<BLOCK, COUNT>(sc, geom, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt);
                 if (!valid) tri = -1;
-                if (tri >= 0) tri_uv(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, oo, dd, u, v); // the winner's own record, this lane's own ray
+                if (tri >= 0) { // the winner's own record, this lane's own ray
+                    float dn;
+                    tri_uv(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, oo, dd, u, v, dn);
+                    tri = with_side(tri, dn);
+                }
             } else {
                 mesh_traverse<BLOCK, COUNT>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt);
             }
@@ -551,7 +562,7 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
         frontFace = false; // Box never reports a front face (Box.cpp:86-89 with PathTracer.cpp:47)
     } else {
         const DMesh& me = sc.meshes[ob.mesh];
-        const float4* s = sc.shade + ((size_t)me.tri_base + (size_t)best.tri) * 7;
+        const float4* s = sc.shade + ((size_t)me.tri_base + (size_t)(best.tri & (kFrontBit - 1))) * 7;
         float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
         f3 pa = mk3(s0.x, s0.y, s0.z), pb = mk3(s0.w, s1.x, s1.y), pc = mk3(s1.z, s1.w, s2.x);
         f3 na = mk3(s2.y, s2.z, s2.w), nb = mk3(s3.x, s3.y, s3.z), nc = mk3(s3.w, s4.x, s4.y);
@@ -559,7 +570,6 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
         float w = 1.0f - u - v;
         f3 pObj = (pa * w + pb * u) + pc * v;
         f3 nObj = normalize((na * w + nb * u) + nc * v);
-        f3 nObjG = normalize(cross(pb - pa, pc - pa));
         float tu = w * s4.z + u * s5.x + v * s5.z, tv = w * s4.w + u * s5.y + v * s5.w;
         p = xform_point(me.m, pObj);
         matIndex = __float_as_int(s6.y); // constant material slot of the face, or -1 (Mesh.cpp:242-246: slot 0 = Material{} defaults)
@@ -590,8 +600,7 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
             else matIndex = g.material; // normal map only: constant material slot
         }
         f3 nW = normalize(xform_normal(me.minv, nObj));
-        f3 ngW = normalize(xform_normal(me.minv, nObjG));
-        frontFace = dot(ray.d, ngW) < 0.0f;
+        frontFace = (best.tri & kFrontBit) != 0; // Mesh.cpp:230-233, see kFrontBit
         n = frontFace ? nW : -nW;
     }
     if (matIndex >= 0) load_material(sc, matIndex, h);
