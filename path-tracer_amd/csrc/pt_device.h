@@ -148,6 +148,8 @@ PT_DEV f3 xform_normal(const float* minv, f3 n)
 // Mesh::RayTriMT (Mesh.cpp:418-445) on the plane form of DTri: same determinant threshold, same t, u, v up to
 // rounding. The distance window of the caller (Mesh.cpp:104) is applied between t and the barycentrics, so a
 // wave whose candidates are all out of range skips the rest. INCLUSIVE: accept t == tHi.
+PT_DEV float plane_coord(float4 q, f3 h) { return fmaf(q.x, h.x, fmaf(q.y, h.y, fmaf(q.z, h.z, q.w))); }      // q.xyz . h + q.w
+PT_DEV float plane_offset(float4 q, f3 o) { return fmaf(-q.x, o.x, fmaf(-q.y, o.y, fmaf(-q.z, o.z, q.w))); } // q.w - q.xyz . o
 template <bool INCLUSIVE>
 PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float tHi, bool quad, float& t, float& u, float& v, float& dn)
 {
@@ -155,12 +157,12 @@ PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float
     f3 n = mk3(q0.x, q0.y, q0.z);
     dn = dot(n, d);
     if (fabsf(dn) < 1e-8f) return false;
-    t = (q0.w - dot(n, o)) * frcp(dn);
+    t = plane_offset(q0, o) * frcp(dn);
     if (!(t > 1e-8f) || t < tLo || (INCLUSIVE ? t > tHi : t >= tHi)) return false;
     f3 h = o + d * t;
-    u = dot(mk3(q1.x, q1.y, q1.z), h) + q1.w;
+    u = plane_coord(q1, h);
     if (u < 0.0f || u > 1.0f) return false;
-    v = dot(mk3(q2.x, q2.y, q2.z), h) + q2.w;
+    v = plane_coord(q2, h);
     // a quad (two triangles forming a parallelogram, this record = the one at corner a) covers the whole unit square
     return !(v < 0.0f || (quad ? v > 1.0f : u + v > 1.0f));
 }
@@ -190,10 +192,10 @@ PT_DEV void tri_uv(const float4* __restrict__ tp, f3 o, f3 d, float& u, float& v
     float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     f3 n = mk3(q0.x, q0.y, q0.z);
     dn = dot(n, d);
-    float t = (q0.w - dot(n, o)) * frcp(dn);
+    float t = plane_offset(q0, o) * frcp(dn);
     f3 h = o + d * t;
-    u = dot(mk3(q1.x, q1.y, q1.z), h) + q1.w;
-    v = dot(mk3(q2.x, q2.y, q2.z), h) + q2.w;
+    u = plane_coord(q1, h);
+    v = plane_coord(q2, h);
 }
 // The side of a triangle that a ray meets travels with the triangle index (bit 30; a mesh has fewer than 2^25
 // faces): Mesh.cpp:160-162,230-233 take it from the sign of direction . MinvT * normalize(e1 x e2), which is the
