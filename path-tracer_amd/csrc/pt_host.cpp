@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -553,7 +554,8 @@ int ptamd_scene_commit(ptamd_scene* s)
     if (int rc = s->d_materials.upload(materials)) return rc;
     if (int rc = s->d_nodes.upload(nodes)) return rc;
     // small scenes are traversed from an LDS copy of their nodes (in LDS format) and hot triangles
-    const bool ldsResident = ldsNodesOk && ldsNodes.size() * 4 + tris.size() * sizeof(DTri) <= kLdsGeomBytes; // scenes without meshes included
+    // scenes without meshes included; PTAMD_NO_LDS_GEOM (read at commit) forces the global-memory kernel for A/B tests
+    const bool ldsResident = ldsNodesOk && ldsNodes.size() * 4 + tris.size() * sizeof(DTri) <= kLdsGeomBytes && !std::getenv("PTAMD_NO_LDS_GEOM");
     if (ldsResident && !ldsNodes.empty()) { if (int rc = s->d_lds_nodes.upload(ldsNodes)) return rc; }
     if (int rc = s->d_tris.upload(tris)) return rc;
     if (int rc = s->d_shade.upload(shade)) return rc;

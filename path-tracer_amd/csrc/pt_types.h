@@ -47,7 +47,8 @@ struct DMesh {
 };
 
 // BVH2 node holding both children's boxes. Child reference: >= 0 -> node index (relative to node_base);
-// < 0 -> leaf: ~ref = (first_triangle << 3) | (count - 1), triangles relative to tri_base.
+// < 0 -> leaf: ~ref = (first_slot << 6) | (quad_mask << 2) | (primitives - 1), slots relative to tri_base; bit i of
+// quad_mask: primitive i is a quad (two adjacent slots tested through the first one's record).
 struct DNode {
     float lmin[3]; float lmax0;     // f4 0: l.min.xyz, l.max.x
     float lmax12[2]; float rmin01[2]; // f4 1: l.max.yz, r.min.xy
