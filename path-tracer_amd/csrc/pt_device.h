@@ -154,6 +154,12 @@ template <bool INCLUSIVE>
 PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float tHi, bool quad, float& t, float& u, float& v, float& dn)
 {
     float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+    if (INCLUSIVE) {
+        // The work-sharing traversal (the INCLUSIVE caller) reads records from global memory: all three reads are
+        // pinned here, before the first early exit, so that a test pays one memory round trip instead of one per
+        // stage (+2 %). From LDS the compiler's choice, one read per stage, is the faster one.
+        asm volatile("" : "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+    }
     f3 n = mk3(q0.x, q0.y, q0.z);
     dn = dot(n, d);
     if (fabsf(dn) < 1e-8f) return false;
