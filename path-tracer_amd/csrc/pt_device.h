@@ -615,12 +615,11 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
     h.p = p; h.n = n; h.frontFace = frontFace;
 }
 
-// GGX half-vector sample (PathTracer.cpp:125-137, 218-235); the azimuth 2*pi*u1 is taken in turns.
-PT_DEV f3 sample_half(float roughness, float alpha, uint32_t key, uint32_t bounce, uint32_t& draw)
+// GGX half-vector sample (PathTracer.cpp:125-137, 218-235) from the two uniforms of this bounce's direction
+// sample; the azimuth 2*pi*u1 is taken in turns.
+PT_DEV f3 sample_half(float roughness, float alpha, float u1, float u2)
 {
     if (roughness <= 1e-4f) return mk3(0, 0, 1);
-    float u1 = rand01(key, bounce, draw), u2 = rand01(key, bounce, draw + 1);
-    draw += 2;
     float a2 = alpha * alpha;
     float tan2t = a2 * u2 * frcp(fmaxf(1e-6f, 1.0f - u2));
     float cosT = frsq(1.0f + tan2t);
@@ -692,39 +691,41 @@ PT_DEV bool sample_bsdf(const HitInfo& h, Ray& ray, float& ior, f3& weight, uint
         specProb = clampf((Fv.x + Fv.y + Fv.z) * (1.0f / 3.0f), 0.05f, 0.95f);
         specular = rand01(key, bounce, draw++) < specProb;
     }
+    // Both lobes draw their direction from the same two counter slots, and both turn a local direction into a
+    // world one through the same frame: the uniforms come before the branch and the frame after it, so a wave
+    // whose lanes split between the lobes (nearly every wave: 5 % of a diffuse surface's samples are specular)
+    // issues them once.
+    const float u1 = rand01(key, bounce, draw), u2 = rand01(key, bounce, draw + 1);
+    f3 local; // sampled direction in the (t, b, n) frame
+    float k;
     if (specular) { // PathTracer.cpp:124-179 (interface reflection) and 213-283 (specular lobe): same GGX sample
-        f3 hL = sample_half(roughness, alpha, key, bounce, draw);
+        f3 hL = sample_half(roughness, alpha, u1, u2);
         float dwh = dot(woL, hL);
-        f3 wiL = hL * (2.0f * dwh) - woL; // reflect(-woL, hL)
-        if (wiL.z <= 0.0f) return false;
-        f3 wi = normalize(t * wiL.x + b * wiL.y + n * wiL.z);
-        float cosNi = fmaxf(0.0f, wiL.z), cosNh = fmaxf(0.0f, hL.z), cosVh = fmaxf(0.0f, dwh);
+        local = hL * (2.0f * dwh) - woL; // reflect(-woL, hL)
+        if (local.z <= 0.0f) return false;
+        float cosNi = fmaxf(0.0f, local.z), cosNh = fmaxf(0.0f, hL.z), cosVh = fmaxf(0.0f, dwh);
         float fp = pow5(1.0f - clampf(cosVh, 0.0f, 1.0f));
         f3 F = mk3(F0.x + (1.0f - F0.x) * fp, F0.y + (1.0f - F0.y) * fp, F0.z + (1.0f - F0.z) * fp);
         float G = smith_g1(cosNo, alpha) * smith_g1(cosNi, alpha);
-        float k = G * cosVh * frcp(fmaxf(1e-6f, cosNo * cosNh));
-        if (interfaceReflect) {
-            k *= frcp(selPdf);
-            ray.o = h.p + wi * kTMin; // offset along the chosen direction, medium unchanged (PathTracer.cpp:174-176)
-        } else {
-            k *= frcp(fmaxf(1e-3f, specProb)) * frcp(fmaxf(1e-3f, 1.0f - pT));
-            ray.o = h.p + n * kTMin;
-            ior = 1.0f; // default-constructed Ray (PathTracer.cpp:278)
-        }
+        k = G * cosVh * frcp(fmaxf(1e-6f, cosNo * cosNh));
+        if (interfaceReflect) k *= frcp(selPdf);
+        else k *= frcp(fmaxf(1e-3f, specProb)) * frcp(fmaxf(1e-3f, 1.0f - pT));
         weight = F * k;
-        ray.d = wi;
-        return true;
+    } else {
+        // Lambert (PathTracer.cpp:284-300) with SampleCosineHemisphereLocal (PathTracer.cpp:19-31)
+        float r = fsqrt(u1);
+        local = mk3(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2), fsqrt(fmaxf(0.0f, 1.0f - u1)));
+        k = om * frcp(fmaxf(1e-3f, 1.0f - specProb)) * frcp(fmaxf(1e-3f, 1.0f - pT));
+        weight = h.albedo * k;
     }
-    // Lambert (PathTracer.cpp:284-300) with SampleCosineHemisphereLocal (PathTracer.cpp:19-31)
-    float u1 = rand01(key, bounce, draw), u2 = rand01(key, bounce, draw + 1);
-    float r = fsqrt(u1);
-    f3 dl = mk3(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2), fsqrt(fmaxf(0.0f, 1.0f - u1)));
-    f3 dw = normalize(t * dl.x + b * dl.y + n * dl.z);
-    float k = om * frcp(fmaxf(1e-3f, 1.0f - specProb)) * frcp(fmaxf(1e-3f, 1.0f - pT));
-    weight = h.albedo * k;
-    ray.o = h.p + n * kTMin;
-    ray.d = dw;
-    ior = 1.0f;
+    f3 wi = normalize(t * local.x + b * local.y + n * local.z);
+    if (interfaceReflect) {
+        ray.o = h.p + wi * kTMin; // offset along the chosen direction, medium unchanged (PathTracer.cpp:174-176)
+    } else {
+        ray.o = h.p + n * kTMin;
+        ior = 1.0f; // default-constructed Ray (PathTracer.cpp:278, 297)
+    }
+    ray.d = wi;
     return true;
 }
 
