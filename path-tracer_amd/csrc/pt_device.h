@@ -51,7 +51,7 @@ struct Ray { f3 o, d; };
 struct Best {
     float t;       // world-space distance (PathTracer.cpp:43 closestT)
     int obj;       // object index, -1 = miss
-    int tri;       // mesh: triangle slot relative to tri_base, | kFrontBit when the ray meets its front side
+    int tri;       // mesh: triangle slot in the scene-wide arrays (tri_base included), | kFrontBit when the ray meets its front side
     float u, v;    // mesh: barycentrics in that triangle's own record
 };
 
@@ -487,7 +487,9 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
             }
             if (tri >= 0) {
                 float tW = closestT * invLen;      // Mesh.cpp:249
-                if (tW < best.t) { best.t = tW; best.obj = i; best.tri = tri; best.u = u; best.v = v; }
+                // the face is kept as an index into the scene-wide arrays: the hit reconstruction can then fetch its shade
+                // record without waiting for the object and mesh records
+                if (tW < best.t) { best.t = tW; best.obj = i; best.tri = tri + (int)me.tri_base; best.u = u; best.v = v; }
             }
         }
     }
@@ -558,19 +560,22 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
     const DObject& ob = sc.objects[best.obj];
     f3 p, n; bool frontFace;
     int matIndex = -1;
-    if (ob.kind != KIND_MESH) load_material(sc, ob.material, h); // issued first: the loads overlap the normal computation
-    if (ob.kind == KIND_SPHERE) {
+    // A mesh hit is known from the hit itself (best.tri >= 0), not from the object record: the shade record of the
+    // face is then fetched side by side with the object and mesh records instead of after them.
+    const bool isMesh = best.tri >= 0;
+    if (!isMesh) load_material(sc, ob.material, h); // issued first: the loads overlap the normal computation
+    if (!isMesh && ob.kind == KIND_SPHERE) {
         p = ray.o + ray.d * best.t;
         f3 outward = (p - mk3(ob.c[0], ob.c[1], ob.c[2])) * frcp(ob.radius);
         frontFace = dot(ray.d, outward) < 0.0f;
         n = frontFace ? outward : -outward;
-    } else if (ob.kind == KIND_BOX) {
+    } else if (!isMesh) {
         p = ray.o + ray.d * best.t;
         n = box_normal(ob, ray, best.t);
         frontFace = false; // Box never reports a front face (Box.cpp:86-89 with PathTracer.cpp:47)
     } else {
         const DMesh& me = sc.meshes[ob.mesh];
-        const float4* s = sc.shade + ((size_t)me.tri_base + (size_t)(best.tri & (kFrontBit - 1))) * 7;
+        const float4* s = sc.shade + (size_t)(best.tri & (kFrontBit - 1)) * 7;
         float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
         f3 pa = mk3(s0.x, s0.y, s0.z), pb = mk3(s0.w, s1.x, s1.y), pc = mk3(s1.z, s1.w, s2.x);
         f3 na = mk3(s2.y, s2.z, s2.w), nb = mk3(s3.x, s3.y, s3.z), nc = mk3(s3.w, s4.x, s4.y);
