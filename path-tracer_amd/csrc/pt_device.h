@@ -48,10 +48,11 @@ PT_DEV float rand01(uint32_t key, uint32_t bounce, uint32_t draw)
 struct Ray { f3 o, d; };
 
 // What the search keeps per lane: enough to rebuild the full Hit for the winner only.
+constexpr int kMeshHit = 1 << 30; // Best::obj of a mesh hit: kMeshHit | index of the mesh instance (DMesh), not the object index
 struct Best {
     float t;       // world-space distance (PathTracer.cpp:43 closestT)
-    int obj;       // object index, -1 = miss
-    int tri;       // mesh: triangle slot in the scene-wide arrays (tri_base included), | kFrontBit when the ray meets its front side
+    int obj;       // object index (sphere, box), kMeshHit | mesh instance index, or -1 = miss
+    int tri;       // mesh hit (obj has kMeshHit): triangle slot in the scene-wide arrays (tri_base included), | kFrontBit when the ray meets its front side
     float u, v;    // mesh: barycentrics in that triangle's own record
 };
 
@@ -489,7 +490,7 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
                 float tW = closestT * invLen;      // Mesh.cpp:249
                 // the face is kept as an index into the scene-wide arrays: the hit reconstruction can then fetch its shade
                 // record without waiting for the object and mesh records
-                if (tW < best.t) { best.t = tW; best.obj = i; best.tri = tri + (int)me.tri_base; best.u = u; best.v = v; }
+                if (tW < best.t) { best.t = tW; best.obj = kMeshHit | ob.mesh; best.tri = tri + (int)me.tri_base; best.u = u; best.v = v; }
             }
         }
     }
@@ -557,12 +558,12 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
     // Every branch leaves its results in these locals and `h` is written once, after the branches join: stores
     // to different fields at the ends of the branches get merged by the compiler into stores through a selected
     // address, which forces those fields into scratch memory.
-    const DObject& ob = sc.objects[best.obj];
+    // A mesh hit names its mesh instance and its face itself (kMeshHit): the instance record and the shade record of
+    // the face are fetched side by side, with no object record before them.
+    const bool isMesh = (best.obj & kMeshHit) != 0;
+    const DObject& ob = sc.objects[isMesh ? 0 : best.obj];
     f3 p, n; bool frontFace;
     int matIndex = -1;
-    // A mesh hit is known from the hit itself (best.tri >= 0), not from the object record: the shade record of the
-    // face is then fetched side by side with the object and mesh records instead of after them.
-    const bool isMesh = best.tri >= 0;
     if (!isMesh) load_material(sc, ob.material, h); // issued first: the loads overlap the normal computation
     if (!isMesh && ob.kind == KIND_SPHERE) {
         p = ray.o + ray.d * best.t;
@@ -574,7 +575,7 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
         n = box_normal(ob, ray, best.t);
         frontFace = false; // Box never reports a front face (Box.cpp:86-89 with PathTracer.cpp:47)
     } else {
-        const DMesh& me = sc.meshes[ob.mesh];
+        const DMesh& me = sc.meshes[best.obj & (kMeshHit - 1)];
         const float4* s = sc.shade + (size_t)(best.tri & (kFrontBit - 1)) * 7;
         float4 s0 = s[0], s1 = s[1], s2 = s[2], s3 = s[3], s4 = s[4], s5 = s[5], s6 = s[6];
         f3 pa = mk3(s0.x, s0.y, s0.z), pb = mk3(s0.w, s1.x, s1.y), pc = mk3(s1.z, s1.w, s2.x);

@@ -226,3 +226,41 @@ def test_mesh_instance_sharing_and_nonuniform_scale(gpu):
     assert ok.sum() >= 0.995 * (ref[:, 0] == 1).sum()
     assert np.abs(got[ok, 5:8] - ref[ok, 5:8]).max() <= 5e-4
     assert np.array_equal(got[ok, 8], ref[ok, 8])
+
+
+def test_sphere_in_front_of_an_earlier_mesh(gpu):
+    """Object order: mesh first, then spheres that hide parts of it. The winner of the closest-hit search must be
+    rebuilt as a sphere although a mesh candidate was found before it (PathTracer.cpp:38-57), and the other way
+    round for a mesh in front of an earlier sphere."""
+    from scenes import gltf_io, presets
+    prim = gltf_io.bumpy_sphere_primitive(6, 8, radius=1.0)
+    idx = prim["indices"].reshape(-1, 3)
+    data = {"positions": prim["positions"][idx].reshape(-1, 9), "normals": prim["normals"][idx].reshape(-1, 9),
+            "uvs": prim["uvs"][idx].reshape(-1, 6), "group": np.zeros(len(idx), np.int32),
+            "groups": [dict(gltf_io.default_pbr(), base_color_factor=[0.2, 0.3, 0.9, 1.0], metallic_factor=0.0, name="m")], "images": []}
+    cam = presets.default_camera()
+    eye = np.asarray(cam["pos"], np.float32)
+    centre = np.array([2.775, 2.2, 2.5], np.float32)
+    toward = (eye - centre) / np.linalg.norm(eye - centre)
+    objs = [{"type": "sphere", "pos": tuple(float(x) for x in centre - 1.5 * toward + np.array([1.2, 0, 0], np.float32)), "radius": 0.7, "mat": presets.material(albedo=(0.9, 0.9, 0.1))},
+            {"type": "mesh", "data": data, "pos": tuple(float(x) for x in centre), "rot": (10.0, 20.0, 0.0), "scale": (1.2, 1.2, 1.2)},
+            {"type": "sphere", "pos": tuple(float(x) for x in centre + 1.3 * toward + np.array([-0.5, 0.3, 0], np.float32)), "radius": 0.6, "mat": presets.material(albedo=(0.9, 0.2, 0.1))}]
+    objs += presets.cornell_room_boxes()
+    scene = {"film": (96, 72), "camera": cam, "objects": objs}
+    pt, camera = gpu.build_scene(scene)
+    S = po.Scene(scene)
+    rays = S.rays()
+    ref = S.closest_hits(rays)
+    got = pt.ClosestHits(rays)
+    assert (got[:, 0] == ref[:, 0]).mean() >= 0.998
+    ok = (got[:, 0] == 1) & (ref[:, 0] == 1) & (np.abs(got[:, 1] - ref[:, 1]) <= 2e-5 * np.abs(ref[:, 1]))
+    assert ok.sum() >= 0.995 * (ref[:, 0] == 1).sum()
+    assert (np.abs(got[ok, 5:8] - ref[ok, 5:8]).max(axis=1) <= 5e-4).mean() >= 0.998
+    assert np.array_equal(got[ok, 9:12], ref[ok, 9:12])  # albedo: the right surface was rebuilt
+    colours = {tuple(float(x) for x in np.round(c.astype(np.float64), 3)) for c in ref[ok, 9:12]}
+    assert (0.9, 0.2, 0.1) in colours and (0.2, 0.3, 0.9) in colours and (0.9, 0.9, 0.1) in colours  # all three are in view
+    film = gpu.Film(96, 72)
+    gpu.Render(camera, pt, film, 2, 4, seed=3)  # the render kernel's own search (LDS-resident scene)
+    oa, _ = S.render(2, 4, seed=3)
+    close = np.abs(film.Accum() - oa).max(axis=-1) <= 1e-3 + 1e-3 * np.abs(oa).max(axis=-1)
+    assert close.mean() >= 0.96, close.mean()
