@@ -177,7 +177,7 @@ def main():
                                "kernel": "render_kernel", "flops_per_sample": flops_per_sample,
                                "executed_flops_per_sample": executed_per_sample, "executed": executed,
                                "executed_frac": executed / FP32_VECTOR_PEAK_TFLOPS,
-                               "note": "fp32 vector ALU bound (no MFMA: not a dense contraction); scene (14 KB) and film "
+                               "note": "fp32 vector ALU bound (no MFMA: not a dense contraction); scene (11 KB in LDS) and film "
                                        "(32 B/pixel/launch) traffic is negligible; `achieved` prices the reference "
                                        "algorithm's counted slab/triangle/box tests and shades on this scene (CPU oracle "
                                        "counters), `executed` the tests this kernel's own BVH walk performed"}
