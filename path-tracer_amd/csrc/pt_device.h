@@ -219,8 +219,9 @@ PT_DEV int hit_triangle(const float4* tris, int slot, bool quad, f3 o, f3 d, flo
     return slot + 1;
 }
 
-// Where the traversal reads BVH nodes (4 float4 each) and hot triangles (3 float4 each) from: the global arrays of
-// the scene, or a copy of them that the workgroup staged into LDS (scenes of a few KB). Same layout in both.
+// Where the traversal reads BVH nodes and hot triangles (3 float4 each) from: the global arrays of the scene
+// (DNode, 4 float4 per node, read by the work-sharing traversal), or the copy that the workgroup staged into LDS
+// for a scene of a few KB (nodes in the LDS format of kLdsNodeBytes, read by mesh_traverse).
 struct Geom { const float4* nodes; const float4* tris; };
 
 // Iterative BVH traversal (replaces the stack walk of Mesh.cpp:79-149), "while-while" form: all lanes of a
@@ -279,7 +280,7 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
                 pop();
             }
         }
-        if (cur < 0) { // leaf: 1..4 primitives; ~ref = first_slot << 6 | quad_mask << 2 | (primitives - 1)
+        if (cur < 0) { // leaf: 1..4 primitives (the builder makes at most 2); ~ref = first_slot << 6 | quad_mask << 2 | (primitives - 1)
             uint32_t code = ~(uint32_t)cur;
             uint32_t slotIdx = code >> 6, mask = (code >> 2) & 15u, prims = (code & 3u) + 1u;
             for (uint32_t i = 0; i < prims; ++i, mask >>= 1) {
