@@ -1,0 +1,63 @@
+// Issue cost of single vector instructions on gfx950: cycles per wave-instruction per SIMD with 8 waves per SIMD,
+// eight independent chains per wave (inline assembly, so the instruction measured is the one named).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+constexpr int ITERS = 8192;
+
+#define KERNEL(name, text)                                                                                        \
+    __global__ __launch_bounds__(256) void name(float* out, float a, float b)                                     \
+    {                                                                                                             \
+        float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7; \
+        for (int i = 0; i < ITERS; ++i) {                                                                         \
+            asm volatile(text : "+v"(x0) : "v"(a), "v"(b)); asm volatile(text : "+v"(x1) : "v"(a), "v"(b));       \
+            asm volatile(text : "+v"(x2) : "v"(a), "v"(b)); asm volatile(text : "+v"(x3) : "v"(a), "v"(b));       \
+            asm volatile(text : "+v"(x4) : "v"(a), "v"(b)); asm volatile(text : "+v"(x5) : "v"(a), "v"(b));       \
+            asm volatile(text : "+v"(x6) : "v"(a), "v"(b)); asm volatile(text : "+v"(x7) : "v"(a), "v"(b));       \
+        }                                                                                                         \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;                      \
+    }
+KERNEL(k_fma, "v_fma_f32 %0, %0, %1, %2")
+KERNEL(k_mul, "v_mul_f32 %0, %0, %1")
+KERNEL(k_add, "v_add_f32 %0, %0, %1")
+KERNEL(k_max, "v_max_f32 %0, %0, %1")
+KERNEL(k_min, "v_min_f32 %0, %0, %1")
+KERNEL(k_max3, "v_max3_f32 %0, %0, %1, %2")
+KERNEL(k_min3, "v_min3_f32 %0, %0, %1, %2")
+KERNEL(k_med3, "v_med3_f32 %0, %0, %1, %2")
+KERNEL(k_imax, "v_max_i32 %0, %0, %1")
+KERNEL(k_imax3, "v_max3_i32 %0, %0, %1, %2")
+KERNEL(k_umin, "v_min_u32 %0, %0, %1")
+KERNEL(k_iadd, "v_add_u32 %0, %0, %1")
+KERNEL(k_and, "v_and_b32 %0, %0, %1")
+KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+KERNEL(k_cmp, "v_cmp_ge_f32 vcc, %0, %1")
+KERNEL(k_rcp, "v_rcp_f32 %0, %0")
+KERNEL(k_mul24, "v_mul_u32_u24 %0, %0, %1")
+KERNEL(k_mullo, "v_mul_lo_u32 %0, %0, %1")
+KERNEL(k_lshladd, "v_lshl_add_u32 %0, %0, 2, %1")
+KERNEL(k_mov, "v_mov_b32 %0, %1")
+
+template <class K> static void run(const char* name, K kernel, float* out)
+{
+    const int blocks = 256 * 8; // 8 workgroups of 4 waves per CU = 8 waves per SIMD
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, a, b));
+    int clockKHz = 0; CHECK(hipDeviceGetAttribute(&clockKHz, hipDeviceAttributeClockRate, 0));
+    const double instrPerSimd = 8.0 * ITERS * 8; // waves per SIMD * iterations * chains
+    printf("  %-14s %8.3f ms  %6.2f cycles per wave-instruction per SIMD (at %.2f GHz)\n", name, ms, ms * 1e-3 * clockKHz * 1e3 / instrPerSimd, clockKHz * 1e-6);
+}
+int main()
+{
+    float* out; CHECK(hipMalloc(&out, 256 * 8 * 256 * 4));
+#define RUN(k) run(#k, k, out)
+    RUN(k_fma); RUN(k_mul); RUN(k_add); RUN(k_max); RUN(k_min); RUN(k_max3); RUN(k_min3); RUN(k_med3); RUN(k_imax); RUN(k_imax3); RUN(k_umin);
+    RUN(k_iadd); RUN(k_and); RUN(k_cndmask); RUN(k_cmp); RUN(k_rcp); RUN(k_mul24); RUN(k_mullo); RUN(k_lshladd); RUN(k_mov);
+    return 0;
+}
