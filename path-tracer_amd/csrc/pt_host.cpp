@@ -466,7 +466,7 @@ int ptamd_scene_commit(ptamd_scene* s)
                 ms.node_base = (uint32_t)nodes.size(); ms.tri_base = (uint32_t)tris.size();
                 ms.group_base = (uint32_t)groups.size(); ms.image_base = (uint32_t)images.size(); ms.flags = 0;
                 nodes.insert(nodes.end(), hm.bvh.nodes.begin(), hm.bvh.nodes.end());
-                if (ldsNodesOk && (ldsNodes.size() * 4 + hm.bvh.nodes.size() * kLdsNodeBytes <= kLdsGeomBytes)) append_lds_nodes(hm.bvh.nodes, ldsNodes);
+                if (ldsNodesOk && (ldsNodes.size() * 4 + hm.bvh.nodes.size() * kLdsNodeBytes <= kLdsBlockBytes)) append_lds_nodes(hm.bvh.nodes, ldsNodes);
                 else ldsNodesOk = false;
                 std::vector<int32_t> faceMaterial; // per group: constant material slot, or -1 when the group samples images
                 for (const ptamd_pbr& g : md.groups) {
@@ -555,7 +555,10 @@ int ptamd_scene_commit(ptamd_scene* s)
     if (int rc = s->d_nodes.upload(nodes)) return rc;
     // small scenes are traversed from an LDS copy of their nodes (in LDS format) and hot triangles
     // scenes without meshes included; PTAMD_NO_LDS_GEOM (read at commit) forces the global-memory kernel for A/B tests
-    const bool ldsResident = ldsNodesOk && ldsNodes.size() * 4 + tris.size() * sizeof(DTri) <= kLdsGeomBytes && !std::getenv("PTAMD_NO_LDS_GEOM");
+    int stackLevels = 1;
+    for (const HostObject& ho : s->objects) if (ho.kind == KIND_MESH) stackLevels = std::max(stackLevels, ho.mesh->bvh.depth);
+    const size_t ldsBlock = (size_t)std::min(stackLevels, maxDepth) * 1024 + kLdsFixedBytes + ldsNodes.size() * 4 + tris.size() * sizeof(DTri);
+    const bool ldsResident = ldsNodesOk && ldsBlock <= kLdsBlockBytes && !std::getenv("PTAMD_NO_LDS_GEOM");
     if (ldsResident && !ldsNodes.empty()) { if (int rc = s->d_lds_nodes.upload(ldsNodes)) return rc; }
     if (int rc = s->d_tris.upload(tris)) return rc;
     if (int rc = s->d_shade.upload(shade)) return rc;

@@ -262,12 +262,12 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     int tiles = rp.tiles_x * rp.tiles_y;
     int blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks <= 0) return hipSuccess;
-    const bool fits = sc.lds_resident != 0; // the host built LDS-format nodes: the scene fits kLdsGeomBytes
+    const bool fits = sc.lds_resident != 0; // the host built LDS-format nodes: the scene fits kLdsBlockBytes
     const size_t geomBytes = fits ? (size_t)(sc.lds_node_f4 + sc.num_tris * 3u) * 16 : 0;
-    if (geomBytes > kLdsGeomBytes) return hipErrorInvalidValue;
     DRenderParams p = rp;
     p.stack_depth = sc.max_stack < 1 ? 1 : (sc.max_stack > kStackDepth ? kStackDepth : sc.max_stack);
     const size_t lds = ((size_t)p.stack_depth * sizeof(StackEntry) + 4 * kLaneFloats + (fits ? 0 : 12)) * kBlock + geomBytes;
+    if (fits && lds > kLdsBlockBytes) return hipErrorInvalidValue; // the host's residency decision uses the same sum
     const bool count = rp.counters != nullptr;
     static const bool debug = getenv("PTAMD_DEBUG") != nullptr;
     const bool ext = (rp.flags & kFlagRoulette) != 0 || sc.sky_size > 0;

@@ -56,7 +56,7 @@ struct DNode {
     int32_t left, right; int32_t pad[2]; // f4 3
 };
 
-// Node of the LDS-resident traversal (scenes whose nodes and hot triangles fit kLdsGeomBytes), built by the host
+// Node of the LDS-resident traversal (scenes whose nodes and hot triangles fit kLdsBlockBytes), built by the host
 // next to the DNode array, one per DNode in the same order, 28 dwords. Per axis eight floats
 // [l.min, r.min, l.max, r.max | l.max, r.max, l.min, r.min] (l, r: the two children's boxes): a ray that travels
 // along +axis reads the first four with one 16-byte read, one that travels along -axis the second four, and either
@@ -64,7 +64,13 @@ struct DNode {
 // the same values (a * inv - o * inv is monotonic in a). Dwords 24, 25: child references, inner ones as byte
 // offsets from the mesh's first node, leaves as in DNode; 26, 27 pad.
 constexpr uint32_t kLdsNodeBytes = 112;
-constexpr uint32_t kLdsGeomBytes = 24576; // LDS nodes + hot triangles of a scene that is traversed from LDS
+// LDS one workgroup of the render kernel may use when the scene's geometry is to live there: a third of the CU's
+// 160 KB. Measured on a 108-triangle room with padded allocations: 5 workgroups per CU 38.8 ms, 4: 44.3, 3: 54.5,
+// 2: 76.9, against 70 ms for the same scene read from global memory; so geometry stays in LDS down to three
+// workgroups per CU. What has to fit: the traversal stack (1 KB per tree level), 3 KB of film sums, the LDS nodes
+// and the hot triangles.
+constexpr uint32_t kLdsBlockBytes = 160 * 1024 / 3;
+constexpr uint32_t kLdsFixedBytes = 3 * 1024; // per workgroup, besides stack and geometry
 
 // Hot triangle in plane form. With n = e1 x e2 (e1 = v1 - v0, e2 = v2 - v0): the determinant of Mesh::RayTriMT
 // (Mesh.cpp:421-431) is -(n . d), its t is (n . v0 - n . o) / (n . d), and the barycentrics of the hit point h
@@ -115,7 +121,7 @@ struct DScene {
     uint32_t num_nodes, num_tris; // totals over all meshes
     const float4* lds_nodes;  // kLdsNodeBytes per node; present when lds_resident
     uint32_t lds_node_f4;     // their size in float4
-    uint32_t lds_resident;    // the LDS nodes and the hot triangles fit kLdsGeomBytes: traverse them from LDS
+    uint32_t lds_resident;    // the LDS nodes and the hot triangles fit kLdsBlockBytes with the stack: traverse them from LDS
     int32_t sky_size; float sky_intensity; // cubemap miss radiance (no reference counterpart): 0 = constant background
     const uint32_t* sky;   // 6 faces (+x -x +y -y +z -z) of sky_size^2 RGBA8 texels, row 0 = top
 };

@@ -198,3 +198,29 @@ def test_lds_and_global_traversal_agree(gpu, monkeypatch):
     oa, _ = po.Scene(scene).render(4, 6, seed=21)
     close = np.abs(lds - oa).max(axis=-1) <= 1e-3 + 1e-3 * np.abs(oa).max(axis=-1)
     assert close.mean() >= 0.95, close.mean()
+
+
+def test_mid_size_mesh_stays_in_lds(gpu, monkeypatch):
+    """A mesh of a few hundred triangles no longer fits the LDS budget of five workgroups per CU but still fits that
+    of three, which is faster than reading it from global memory: it must take the LDS kernel (no steal rounds, the
+    mark of the work-sharing kernel) and give the same radiance as the global-memory kernel."""
+    prim = gltf_io.bumpy_sphere_primitive(10, 14, radius=1.0, bump=0.05, freq=5)
+    data = soup(prim)
+    assert 250 <= data["positions"].shape[0] <= 300
+    objs = presets.cornell_room_boxes()
+    objs.append({"type": "mesh", "data": data, "pos": (2.775, 2.0, 2.8), "rot": (10.0, 30.0, 0.0), "scale": (1.6, 1.6, 1.6)})
+    scene = {"film": (96, 72), "camera": presets.default_camera(), "objects": objs}
+    pt, cam = gpu.build_scene(scene)
+    film = gpu.Film(96, 72)
+    gpu.Render(cam, pt, film, 4, 6, seed=9, count=True)
+    stats = gpu.RenderStats()
+    assert stats["steal_rounds"] == 0 and stats["nodes"] > 0
+    lds = film.Accum()
+    monkeypatch.setenv("PTAMD_NO_LDS_GEOM", "1")
+    pt2, _ = gpu.build_scene(scene)
+    film2 = gpu.Film(96, 72)
+    gpu.Render(cam, pt2, film2, 4, 6, seed=9, count=True)
+    assert gpu.RenderStats()["steal_rounds"] > 0
+    glob = film2.Accum()
+    close = np.abs(lds - glob).max(axis=-1) <= 1e-4 + 1e-4 * np.abs(glob).max(axis=-1)
+    assert close.mean() >= 0.99, close.mean()

@@ -31,9 +31,11 @@ def main():
         "glass_mirror": (presets.glass_mirror(1920, 1080), 32),
         "blob_mixed": (presets.mixed("tests/golden/blob.glb", 1920, 1080, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0)), 8),
     }
-    if "bumpy_1m" in args.scenes.split(","):
+    for name, (rings, segments) in {"bumpy_1m": (500, 1000), "bumpy_280": (10, 14)}.items():
+        if name not in args.scenes.split(","):
+            continue
         from scenes import gltf_io
-        prim = gltf_io.bumpy_sphere_primitive(500, 1000, radius=1.0, bump=0.06, freq=9)
+        prim = gltf_io.bumpy_sphere_primitive(rings, segments, radius=1.0, bump=0.06, freq=9 if rings > 100 else 5)
         idx = prim["indices"].reshape(-1, 3)
         data = {"positions": np.ascontiguousarray(prim["positions"][idx].reshape(-1, 9)),
                 "normals": np.ascontiguousarray(prim["normals"][idx].reshape(-1, 9)),
@@ -43,7 +45,7 @@ def main():
                 "images": []}
         objs = presets.cornell_room_boxes()
         objs.append({"type": "mesh", "data": data, "pos": (2.775, 2.2, 2.2), "rot": (20.0, 30.0, 0.0), "scale": (2.3, 2.0, 2.1)})
-        table["bumpy_1m"] = ({"film": (1920, 1080), "camera": presets.default_camera(), "background": (0.2, 0.2, 0.2), "objects": objs}, 8)
+        table[name] = ({"film": (1920, 1080), "camera": presets.default_camera(), "background": (0.2, 0.2, 0.2), "objects": objs}, 8)
     for name in args.scenes.split(","):
         scene, depth = table[name]
         w, h = scene["film"]
