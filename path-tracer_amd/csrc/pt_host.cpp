@@ -548,6 +548,8 @@ int ptamd_scene_commit(ptamd_scene* s)
         objects.push_back(d);
     }
 
+    // a hit names its face by its index in the scene-wide arrays with two flag bits above it (pt_device.h: kFrontBit)
+    if (tris.size() >= (size_t(1) << 30)) return fail(PTAMD_ERR_LIMIT, "scene has too many triangles (limit 2^30 - 1 over all distinct meshes)");
     s->release();
     if (int rc = s->d_objects.upload(objects)) return rc;
     if (int rc = s->d_meshes.upload(meshes)) return rc;
