@@ -264,3 +264,76 @@ def test_sphere_in_front_of_an_earlier_mesh(gpu):
     oa, _ = S.render(2, 4, seed=3)
     close = np.abs(film.Accum() - oa).max(axis=-1) <= 1e-3 + 1e-3 * np.abs(oa).max(axis=-1)
     assert close.mean() >= 0.96, close.mean()
+
+
+# PTAMD_FUZZ_SEEDS="100-160" widens the run for a one-off fuzzing session
+def _fuzz_seeds():
+    import os
+    seeds = [11, 12, 13, 14, 15, 16]
+    extra = os.environ.get("PTAMD_FUZZ_SEEDS")
+    if extra:
+        lo, hi = (int(x) for x in extra.split("-"))
+        seeds += list(range(lo, hi + 1))
+    return seeds
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
+def test_random_scenes_match_oracle(gpu, seed):
+    """Randomly composed scenes: spheres, boxes and meshes in random order with random transforms and materials
+    (diffuse, metal, glass, emitters), small enough for LDS on even seeds and with a mesh of ~2000 triangles (global
+    memory, work-sharing traversal) on odd ones. Closest hits and same-seed radiance must match the oracle."""
+    from scenes import gltf_io, presets
+    rng = np.random.default_rng(seed)
+
+    def mesh_data(rings, segments, colour):
+        prim = gltf_io.bumpy_sphere_primitive(rings, segments, radius=1.0, bump=0.08, freq=4)
+        idx = prim["indices"].reshape(-1, 3)
+        return {"positions": np.ascontiguousarray(prim["positions"][idx].reshape(-1, 9)), "normals": np.ascontiguousarray(prim["normals"][idx].reshape(-1, 9)),
+                "uvs": np.ascontiguousarray(prim["uvs"][idx].reshape(-1, 6)), "group": np.zeros(len(idx), np.int32),
+                "groups": [dict(gltf_io.default_pbr(), base_color_factor=list(colour) + [1.0], metallic_factor=float(rng.random() < 0.3),
+                                roughness_factor=float(rng.uniform(0.05, 1.0)), name="m")], "images": []}
+
+    def rand_material():
+        kind = rng.integers(0, 4)
+        albedo = tuple(float(x) for x in rng.uniform(0.1, 0.9, 3))
+        if kind == 0:
+            return presets.material(albedo=albedo, roughness=float(rng.uniform(0.2, 1.0)))
+        if kind == 1:
+            return presets.material(albedo=albedo, roughness=float(rng.uniform(0.0, 0.4)), metallic=1.0)
+        if kind == 2:
+            return presets.material(albedo=(1, 1, 1), roughness=0.0, ior=1.5, transmission=1.0)
+        return presets.material(albedo=albedo, emission_colour=(1.0, 0.9, 0.7), emission_strength=float(rng.uniform(1.0, 6.0)))
+
+    small = mesh_data(5, 6, rng.uniform(0.2, 0.9, 3))
+    other = mesh_data(20, 50, rng.uniform(0.2, 0.9, 3)) if seed % 2 else mesh_data(4, 5, rng.uniform(0.2, 0.9, 3))
+    objs = []
+    for _ in range(int(rng.integers(5, 10))):
+        pos = tuple(float(x) for x in rng.uniform((0.8, 0.6, 1.0), (4.8, 4.4, 4.6)))
+        rot = tuple(float(x) for x in rng.uniform(-180, 180, 3))
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            objs.append({"type": "sphere", "pos": pos, "radius": float(rng.uniform(0.3, 0.9)), "mat": rand_material()})
+        elif kind == 1:
+            objs.append({"type": "box", "pos": pos, "rot": rot, "size": tuple(float(x) for x in rng.uniform(0.4, 1.4, 3)), "mat": rand_material()})
+        else:
+            objs.append({"type": "mesh", "data": small if kind == 2 else other, "pos": pos, "rot": rot,
+                         "scale": tuple(float(x) for x in rng.uniform(0.4, 1.1, 3))})
+    room = presets.cornell_room_boxes()
+    cut = int(rng.integers(0, len(objs) + 1))
+    scene = {"film": (72, 54), "camera": presets.default_camera(), "objects": objs[:cut] + room + objs[cut:]}
+    pt, cam = gpu.build_scene(scene)
+    S = po.Scene(scene)
+    rays = S.rays()
+    ref = S.closest_hits(rays)
+    got = pt.ClosestHits(rays)
+    assert (got[:, 0] == ref[:, 0]).mean() >= 0.998
+    both = (got[:, 0] == 1) & (ref[:, 0] == 1)
+    same = both & (np.abs(got[:, 1] - ref[:, 1]) <= 2e-5 * np.abs(ref[:, 1]) + 1e-6) & np.all(got[:, 9:14] == ref[:, 9:14], axis=1)
+    assert same.sum() >= 0.99 * both.sum(), (same.sum(), both.sum())
+    assert (np.abs(got[same, 5:8] - ref[same, 5:8]).max(axis=1) <= 5e-4).mean() >= 0.995
+    assert np.array_equal(got[same, 8], ref[same, 8])
+    film = gpu.Film(72, 54)
+    gpu.Render(cam, pt, film, 2, 6, seed=seed)
+    oa, _ = S.render(2, 6, seed=seed)
+    close = np.abs(film.Accum() - oa).max(axis=-1) <= 2e-3 + 2e-3 * np.abs(oa).max(axis=-1)
+    assert close.mean() >= 0.94, close.mean()
