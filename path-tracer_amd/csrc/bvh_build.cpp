@@ -236,7 +236,12 @@ BvhResult build_bvh(const float* P, const int32_t* group, uint32_t n, int max_de
     Builder b;
     b.maxDepth = max_depth;
     Box3 all; all.reset();
-    for (uint32_t i = 0; i < n; ++i) { const float* p = P + 9 * (size_t)i; all.grow(p); all.grow(p + 3); all.grow(p + 6); }
+    // A triangle with a non-finite coordinate can never be hit (every comparison of Mesh::RayTriMT fails on NaN); it
+    // stays in the tree as an inert primitive with an empty box, so that it cannot poison bounds, tolerances or the
+    // ordering of the sorts.
+    auto finite_tri = [&](uint32_t f) { for (int k = 0; k < 9; ++k) if (!std::isfinite(P[9 * (size_t)f + k])) return false; return true; };
+    for (uint32_t i = 0; i < n; ++i) { if (!finite_tri(i)) continue; const float* p = P + 9 * (size_t)i; all.grow(p); all.grow(p + 3); all.grow(p + 6); }
+    if (all.lo[0] > all.hi[0]) for (int k = 0; k < 3; ++k) all.lo[k] = all.hi[k] = 0.f; // no finite triangle at all
     float scale = 0.f;
     for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(all.lo[k]), std::fabs(all.hi[k])));
     const bool quads = !std::getenv("PTAMD_NO_QUADS");
@@ -247,6 +252,13 @@ BvhResult build_bvh(const float* P, const int32_t* group, uint32_t n, int max_de
     for (uint32_t i = 0; i < np; ++i) {
         Box3 t; t.reset();
         const float* p = P + 9 * (size_t)b.primA[i];
+        if (!finite_tri(b.primA[i]) || (b.primB[i] != Builder::kNone && !finite_tri(b.primB[i]))) {
+            if (b.primB[i] != Builder::kNone) ++res.num_quads;
+            b.fb[i] = t; // empty
+            for (int k = 0; k < 3; ++k) b.fc[3 * (size_t)i + k] = 0.f;
+            b.idx[i] = i;
+            continue;
+        }
         t.grow(p); t.grow(p + 3); t.grow(p + 6);
         if (b.primB[i] != Builder::kNone) { const float* q = P + 9 * (size_t)b.primB[i]; t.grow(q); t.grow(q + 3); t.grow(q + 6); ++res.num_quads; }
         b.fb[i] = t;

@@ -224,3 +224,37 @@ def test_mid_size_mesh_stays_in_lds(gpu, monkeypatch):
     glob = film2.Accum()
     close = np.abs(lds - glob).max(axis=-1) <= 1e-4 + 1e-4 * np.abs(glob).max(axis=-1)
     assert close.mean() >= 0.99, close.mean()
+
+
+def test_non_finite_triangles_are_inert(gpu):
+    """Triangles with NaN or infinite coordinates can never be hit (Mesh.cpp:418-445: every comparison fails) and must
+    not disturb the others: same closest hits and radiance as the mesh without them, on both traversal kernels."""
+    for rings, segments in [(5, 6), (24, 40)]:  # LDS-resident / global memory
+        good = soup(gltf_io.bumpy_sphere_primitive(rings, segments, radius=1.0, bump=0.05, freq=3))
+        bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in good.items()}
+        n = good["positions"].shape[0]
+        extra = good["positions"][:4].copy()
+        extra[0, 4] = np.nan; extra[1, 0] = np.inf; extra[2, :] = np.nan; extra[3, 8] = -np.inf
+        where = [0, n // 3, n // 2, n]
+        for key, rows in (("positions", extra), ("normals", good["normals"][:4]), ("uvs", good["uvs"][:4])):
+            a = good[key]
+            for i, w in enumerate(where):
+                a = np.insert(a, w + i, rows[i], axis=0)
+            bad[key] = np.ascontiguousarray(a)
+        bad["group"] = np.zeros(n + 4, np.int32)
+        out = []
+        for data in (good, bad):
+            objs = presets.cornell_room_boxes()
+            objs.append({"type": "mesh", "data": data, "pos": (2.775, 2.0, 2.8), "rot": (10.0, 30.0, 0.0), "scale": (1.5, 1.5, 1.5)})
+            scene = {"film": (64, 48), "camera": presets.default_camera(), "objects": objs}
+            pt, cam = gpu.build_scene(scene)
+            hits = pt.ClosestHits(cam.GetRays().reshape(-1, 6))
+            film = gpu.Film(64, 48)
+            gpu.Render(cam, pt, film, 2, 5, seed=4)
+            out.append((hits, film.Accum()))
+        (ha, fa), (hb, fb) = out
+        assert np.array_equal(ha[:, 0], hb[:, 0])
+        assert np.isfinite(hb).all() and np.isfinite(fb).all()
+        assert np.abs(ha[:, 1:8] - hb[:, 1:8]).max() <= 1e-5
+        close = np.abs(fa - fb).max(axis=-1) <= 1e-4 + 1e-4 * np.abs(fa).max(axis=-1)
+        assert close.mean() >= 0.99, close.mean()
