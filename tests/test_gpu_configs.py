@@ -258,3 +258,36 @@ def test_non_finite_triangles_are_inert(gpu):
         assert np.abs(ha[:, 1:8] - hb[:, 1:8]).max() <= 1e-5
         close = np.abs(fa - fb).max(axis=-1) <= 1e-4 + 1e-4 * np.abs(fa).max(axis=-1)
         assert close.mean() >= 0.99, close.mean()
+
+
+@pytest.mark.parametrize("faces", [1, 2, 3])
+def test_tiny_meshes(gpu, faces, monkeypatch):
+    """One triangle (the tree is a single leaf), a quad (one primitive) and three triangles (quad + triangle), with a
+    zero-area triangle among them: closest hits as the oracle's, from LDS and from global memory."""
+    tri = np.array([[-1, -1, 0, 1, -1, 0, 1, 1, 0], [-1, -1, 0, 1, 1, 0, -1, 1, 0], [1, -1, 0, 2, 0, 0.5, 1, 1, 0]], np.float32)[:faces]
+    tri = np.concatenate([tri, np.array([[0.5, 0.5, 1, 0.5, 0.5, 1, 0.5, 0.5, 1]], np.float32)])  # degenerate: never hit
+    nrm = np.tile(np.array([0, 0, -1], np.float32), (len(tri), 3))
+    data = {"positions": tri, "normals": nrm, "uvs": np.zeros((len(tri), 6), np.float32), "group": np.zeros(len(tri), np.int32),
+            "groups": [dict(gltf_io.default_pbr(), base_color_factor=[0.9, 0.5, 0.1, 1.0], metallic_factor=0.0, name="m")], "images": []}
+    objs = presets.cornell_room_boxes()
+    objs.append({"type": "mesh", "data": data, "pos": (2.775, 2.5, 3.0), "rot": (0.0, 15.0, 0.0), "scale": (1.2, 1.2, 1.2)})
+    scene = {"film": (64, 48), "camera": presets.default_camera(), "objects": objs}
+    S = po.Scene(scene)
+    rays = S.rays()
+    ref = S.closest_hits(rays)
+    on_mesh = np.all(np.abs(ref[:, 9:12] - np.array([0.9, 0.5, 0.1], np.float32)) < 1e-6, axis=1) & (ref[:, 0] == 1)
+    assert on_mesh.sum() > 50
+    oa, _ = S.render(2, 4, seed=2)
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("PTAMD_NO_LDS_GEOM", env)
+        pt, cam = gpu.build_scene(scene)
+        got = pt.ClosestHits(rays)
+        assert (got[:, 0] == ref[:, 0]).mean() >= 0.998
+        same = (got[:, 0] == 1) & (ref[:, 0] == 1) & (np.abs(got[:, 1] - ref[:, 1]) <= 2e-5 * np.abs(ref[:, 1])) & np.all(got[:, 9:12] == ref[:, 9:12], axis=1)
+        assert same.sum() >= 0.995 * (ref[:, 0] == 1).sum()
+        assert np.array_equal(got[same, 8], ref[same, 8])
+        film = gpu.Film(64, 48)
+        gpu.Render(cam, pt, film, 2, 4, seed=2)
+        close = np.abs(film.Accum() - oa).max(axis=-1) <= 2e-3 + 2e-3 * np.abs(oa).max(axis=-1)
+        assert close.mean() >= 0.95, close.mean()
