@@ -76,14 +76,25 @@ PT_DEV float sphere_t(const DObject& ob, const Ray& r, float tMin, float tMax)
 }
 
 struct BoxLocal { f3 ro, rd, tMin3; float tEntry, tExit; };
-// Box::RayIntersect steps 1-4 (Box.cpp:16-48).
+// Box::RayIntersect steps 1-4 (Box.cpp:16-48). SHORTCUT (the search loop; not the one call per hit of box_normal): an
+// unrotated box (DObject::aligned, the walls of a room) has the world axes as its own, so its local ray is
+// (origin - centre, direction); the six dot products with unit axes that this skips return these same values.
+template <bool SHORTCUT>
 PT_DEV BoxLocal box_slabs(const DObject& ob, const Ray& r)
 {
     BoxLocal b;
-    f3 a0 = mk3(ob.ax0[0], ob.ax0[1], ob.ax0[2]), a1 = mk3(ob.ax1[0], ob.ax1[1], ob.ax1[2]), a2 = mk3(ob.ax2[0], ob.ax2[1], ob.ax2[2]);
     f3 v = r.o - mk3(ob.c[0], ob.c[1], ob.c[2]);
-    b.ro = mk3(dot(a0, v), dot(a1, v), dot(a2, v));
-    b.rd = mk3(dot(a0, r.d), dot(a1, r.d), dot(a2, r.d));
+    if (SHORTCUT && ob.aligned) {
+        // + pad1 (a zero the compiler cannot see through): without it the reciprocals below are loop-invariant and
+        // get hoisted out of the object loop, where they cost three registers and three v_rcp per ray in scenes
+        // that have no box at all
+        const float zero = ob.pad1;
+        b.ro = v; b.rd = mk3(r.d.x + zero, r.d.y + zero, r.d.z + zero);
+    } else {
+        f3 a0 = mk3(ob.ax0[0], ob.ax0[1], ob.ax0[2]), a1 = mk3(ob.ax1[0], ob.ax1[1], ob.ax1[2]), a2 = mk3(ob.ax2[0], ob.ax2[1], ob.ax2[2]);
+        b.ro = mk3(dot(a0, v), dot(a1, v), dot(a2, v));
+        b.rd = mk3(dot(a0, r.d), dot(a1, r.d), dot(a2, r.d));
+    }
     const float BIG = 1e30f;
     f3 inv = mk3(b.rd.x != 0.0f ? frcp(b.rd.x) : -BIG, b.rd.y != 0.0f ? frcp(b.rd.y) : -BIG, b.rd.z != 0.0f ? frcp(b.rd.z) : -BIG);
     f3 he = mk3(ob.half[0], ob.half[1], ob.half[2]);
@@ -97,7 +108,7 @@ PT_DEV BoxLocal box_slabs(const DObject& ob, const Ray& r)
 // Box.cpp:50-54: returns tHit or -1.
 PT_DEV float box_t(const DObject& ob, const Ray& r, float tMin, float tMax)
 {
-    BoxLocal b = box_slabs(ob, r);
+    BoxLocal b = box_slabs<true>(ob, r);
     if (b.tExit < b.tEntry) return -1.0f;
     if (b.tExit < tMin) return -1.0f;
     float tHit = b.tEntry;
@@ -108,7 +119,7 @@ PT_DEV float box_t(const DObject& ob, const Ray& r, float tMin, float tMax)
 // Box.cpp:56-83: world normal (face-forwarded) for the winning hit.
 PT_DEV f3 box_normal(const DObject& ob, const Ray& r, float tHit)
 {
-    BoxLocal b = box_slabs(ob, r);
+    BoxLocal b = box_slabs<false>(ob, r);
     f3 pL = b.ro + b.rd * tHit;
     f3 he = mk3(ob.half[0], ob.half[1], ob.half[2]);
     float eps = ob.eps;

@@ -450,6 +450,8 @@ int ptamd_scene_commit(ptamd_scene* s)
             d.eps = 1e-4f * std::max(std::max(d.half[0], d.half[1]), d.half[2]);          // Box.cpp:63
             Mat4 R = rotate_euler_xyz(Mat4::identity(), ho.rot);                          // Box.cpp:16-19
             for (int k = 0; k < 3; ++k) { d.ax0[k] = R.m[0][k]; d.ax1[k] = R.m[1][k]; d.ax2[k] = R.m[2][k]; }
+            d.aligned = d.ax0[0] == 1.f && d.ax0[1] == 0.f && d.ax0[2] == 0.f && d.ax1[0] == 0.f && d.ax1[1] == 1.f && d.ax1[2] == 0.f
+                        && d.ax2[0] == 0.f && d.ax2[1] == 0.f && d.ax2[2] == 1.f;
             d.material = (int32_t)materials.size(); materials.push_back(to_dmaterial(ho.mat));
         } else {
             HostMesh& hm = *ho.mesh;

@@ -24,7 +24,8 @@ struct DMaterial {
 
 // One entry per RayObject, in AddRayObject order (the closest-hit loop keeps the first of equal hits).
 struct DObject {
-    int32_t kind, material, mesh, pad0;
+    int32_t kind, material, mesh;
+    int32_t aligned;                // box whose axes are the world axes (no rotation): its local ray is origin - centre, direction
     float c[3]; float radius;       // sphere/box centre; sphere radius
     float half[3]; float eps;       // box half extents; face epsilon = 1e-4 * max half extent (Box.cpp:63)
     float ax0[3]; float pad1;       // box axes = columns of worldFromLocal (Box.cpp:16-23)
