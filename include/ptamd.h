@@ -196,6 +196,13 @@ int ptamd_film_device_ptrs(ptamd_film* f, void** d_accum, void** d_samples);
  * Asynchronous on the library stream; film reads synchronise. */
 int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
                  int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags);
+/* The same for one rank's share of an interleaved tile split, in ONE launch: the film is cut into square tiles of
+ * tile_size pixels (a multiple of 8), numbered row-major, and the call renders the tiles tile_phase,
+ * tile_phase + tile_stride, ... (rank and world size of a multi-GPU job).  It generalises the row-band task split of
+ * RayTraceParallel (main.cpp:33-46: numTasks bands handed to a thread pool) to ranks; per-sample values are those of
+ * ptamd_render, so the films of all phases sum to the single-launch film bit for bit. */
+int ptamd_render_tiles(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
+                       int depth, int albedo_only, uint32_t seed, int tile_size, int tile_phase, int tile_stride, uint32_t flags);
 int ptamd_render_stats(ptamd_stats* out); /* synchronises */
 
 /* ---- probes used by the parity tests ------------------------------------------------------- */

@@ -726,8 +726,9 @@ int ptamd_film_device_ptrs(ptamd_film* f, void** a, void** s)
 }
 
 // ------------------------------------------------------------------------------- render
-int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
-                 int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags)
+static int render_impl(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
+                       int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags,
+                       int tile_size, int tile_phase, int tile_stride)
 {
     if (!s || !cam || !f) return fail(PTAMD_ERR_ARG, "null argument");
     if (int rc = need_init()) return rc;
@@ -748,12 +749,32 @@ int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_
     rp.spp_begin = spp_begin; rp.spp_count = spp_count;
     rp.depth = depth; rp.albedo_only = albedo_only ? 1 : 0; rp.seed = seed; rp.flags = flags;
     rp.tiles_x = (rp.x1 - rp.x0 + 7) / 8; rp.tiles_y = (rp.y1 - rp.y0 + 7) / 8;
+    if (tile_stride > 0) {
+        const int cols = (f->w + tile_size - 1) / tile_size, rows = (f->h + tile_size - 1) / tile_size;
+        const long long total = (long long)cols * rows;
+        if (tile_phase >= total) return PTAMD_OK; // this rank owns no tile
+        rp.tile_size = tile_size; rp.tile_phase = tile_phase; rp.tile_stride = tile_stride; rp.tile_cols = cols;
+        rp.tile_side = tile_size / 8; rp.tile_waves = rp.tile_side * rp.tile_side;
+        rp.tiles_owned = (int)((total - tile_phase + tile_stride - 1) / tile_stride);
+    }
     if (depth <= 0) {
         // TraceRay returns 0 at once (PathTracer.cpp:35-36): every sample adds black
         rp.depth = 0;
     }
     PT_HIP(launch_render(s->dscene, rp, g_stream));
     return PTAMD_OK;
+}
+int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
+                 int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags)
+{
+    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, rect, flags, 0, 0, 0);
+}
+int ptamd_render_tiles(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
+                       int depth, int albedo_only, uint32_t seed, int tile_size, int tile_phase, int tile_stride, uint32_t flags)
+{
+    if (tile_size < 8 || tile_size % 8 != 0 || tile_size > 4096) return fail(PTAMD_ERR_ARG, "tile_size must be a multiple of 8 in [8, 4096]");
+    if (tile_stride < 1 || tile_phase < 0 || tile_phase >= tile_stride) return fail(PTAMD_ERR_ARG, "need 0 <= tile_phase < tile_stride");
+    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, nullptr, flags, tile_size, tile_phase, tile_stride);
 }
 int ptamd_render_stats(ptamd_stats* out)
 {

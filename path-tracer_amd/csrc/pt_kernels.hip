@@ -60,7 +60,7 @@ constexpr int kNumCounters = 10;        // fields of ptamd_stats, in order
 #define PT_WAVES_COOP 4 // the cooperative traversal needs ~112 VGPRs; spilling them costs more than the fifth wave brings
 #endif
 constexpr int kLaneFloats = 3;          // per-lane floats parked in LDS: the film sum of the lane's pixel
-template <bool LDS_GEOM, bool COUNT, bool EXT>
+template <bool LDS_GEOM, bool COUNT, bool EXT, bool TILED>
 __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void render_kernel(DScene sc, DRenderParams rp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -77,10 +77,22 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
     const Geom geom = stage_geometry<LDS_GEOM>(sc, lds_geom);
     const int slot = threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const int tx = tile % rp.tiles_x, ty = tile / rp.tiles_x;
-    const int px = rp.x0 + tx * 8 + (lane & 7), py = rp.y0 + ty * 8 + (lane >> 3);
-    const bool inside = (ty < rp.tiles_y) && (px < rp.x1) && (py < rp.y1);
+    const int tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); // this wave's 8x8 tile, in launch order
+    int px, py; bool inside;
+    if (TILED) {
+        // Interleaved square tiles of one rank (ptamd_render_tiles): wave-tiles are numbered through the owned tiles one
+        // after the other. A build of its own: the same lines in the rect kernel's prologue moved its loops by 260
+        // bytes and cost it 2 % (identical loop code, different placement).
+        const int owned = tile / rp.tile_waves, sub = tile % rp.tile_waves;
+        const int big = rp.tile_phase + owned * rp.tile_stride;
+        const int bx = big % rp.tile_cols, by = big / rp.tile_cols;
+        px = bx * rp.tile_size + (sub % rp.tile_side) * 8 + (lane & 7); py = by * rp.tile_size + (sub / rp.tile_side) * 8 + (lane >> 3);
+        inside = (owned < rp.tiles_owned) && (px < rp.x1) && (py < rp.y1);
+    } else {
+        const int tx = tile % rp.tiles_x, ty = tile / rp.tiles_x;
+        px = rp.x0 + tx * 8 + (lane & 7); py = rp.y0 + ty * 8 + (lane >> 3);
+        inside = (ty < rp.tiles_y) && (px < rp.x1) && (py < rp.y1);
+    }
     const int W = rp.cam.width;
     const uint32_t pixel = (uint32_t)(py * W + px);
 
@@ -259,7 +271,8 @@ __global__ void resolve_kernel(const float* accum, const uint32_t* samples, int 
 // ---------------------------------------------------------------- launchers (called from pt_host.cpp)
 hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t stream)
 {
-    int tiles = rp.tiles_x * rp.tiles_y;
+    const bool tiled = rp.tile_stride > 0;
+    int tiles = tiled ? rp.tiles_owned * rp.tile_waves : rp.tiles_x * rp.tiles_y; // 8x8 wave-tiles of the launch
     int blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks <= 0) return hipSuccess;
     const bool fits = sc.lds_resident != 0; // the host built LDS-format nodes: the scene fits kLdsBlockBytes
@@ -271,25 +284,33 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const bool count = rp.counters != nullptr;
     static const bool debug = getenv("PTAMD_DEBUG") != nullptr;
     const bool ext = (rp.flags & kFlagRoulette) != 0 || sc.sky_size > 0;
-#define PT_LAUNCH(LDSG, COUNT, EXT)                                                                                   \
+#define PT_LAUNCH(LDSG, COUNT, EXT, TILED)                                                                                   \
     do {                                                                                                              \
         if (debug) {                                                                                                  \
             int nb = 0;                                                                                               \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<LDSG, COUNT, EXT>, kBlock, lds);    \
-            fprintf(stderr, "ptamd: render_kernel<%d,%d,%d> stack %d, lds %zu B/block, %d blocks/CU resident\n", (int)LDSG, (int)COUNT, (int)EXT, p.stack_depth, lds, nb); \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<LDSG, COUNT, EXT, TILED>, kBlock, lds);    \
+            fprintf(stderr, "ptamd: render_kernel<%d,%d,%d,%d> stack %d, lds %zu B/block, %d blocks/CU resident\n", (int)LDSG, (int)COUNT, (int)EXT, (int)TILED, p.stack_depth, lds, nb); \
         }                                                                                                             \
-        hipLaunchKernelGGL((render_kernel<LDSG, COUNT, EXT>), dim3(blocks), dim3(kBlock), lds, stream, sc, p);        \
+        hipLaunchKernelGGL((render_kernel<LDSG, COUNT, EXT, TILED>), dim3(blocks), dim3(kBlock), lds, stream, sc, p);        \
     } while (0)
-    const int variant = (fits ? 4 : 0) | (count ? 2 : 0) | (ext ? 1 : 0);
+    const int variant = (tiled ? 8 : 0) | (fits ? 4 : 0) | (count ? 2 : 0) | (ext ? 1 : 0);
     switch (variant) {
-    case 0: PT_LAUNCH(false, false, false); break;
-    case 1: PT_LAUNCH(false, false, true); break;
-    case 2: PT_LAUNCH(false, true, false); break;
-    case 3: PT_LAUNCH(false, true, true); break;
-    case 4: PT_LAUNCH(true, false, false); break;
-    case 5: PT_LAUNCH(true, false, true); break;
-    case 6: PT_LAUNCH(true, true, false); break;
-    default: PT_LAUNCH(true, true, true); break;
+    case 0: PT_LAUNCH(false, false, false, false); break;
+    case 1: PT_LAUNCH(false, false, true, false); break;
+    case 2: PT_LAUNCH(false, true, false, false); break;
+    case 3: PT_LAUNCH(false, true, true, false); break;
+    case 4: PT_LAUNCH(true, false, false, false); break;
+    case 5: PT_LAUNCH(true, false, true, false); break;
+    case 6: PT_LAUNCH(true, true, false, false); break;
+    case 7: PT_LAUNCH(true, true, true, false); break;
+    case 8: PT_LAUNCH(false, false, false, true); break;
+    case 9: PT_LAUNCH(false, false, true, true); break;
+    case 10: PT_LAUNCH(false, true, false, true); break;
+    case 11: PT_LAUNCH(false, true, true, true); break;
+    case 12: PT_LAUNCH(true, false, false, true); break;
+    case 13: PT_LAUNCH(true, false, true, true); break;
+    case 14: PT_LAUNCH(true, true, false, true); break;
+    default: PT_LAUNCH(true, true, true, true); break;
     }
 #undef PT_LAUNCH
     return hipGetLastError();

@@ -145,6 +145,11 @@ struct DRenderParams {
     uint32_t seed, flags;  // flags: PTAMD_FLAG_* of the public header
     int32_t tiles_x, tiles_y; // 8x8-pixel tiles covering the rect
     int32_t stack_depth, pad; // rows of the per-lane traversal stack in LDS (set by the launcher)
+    // Interleaved-tile launches (tile_stride > 0, ptamd_render_tiles) cover, instead of the rect, the square tiles of
+    // tile_size pixels (a multiple of 8) whose row-major index is tile_phase + k * tile_stride, k < tiles_owned;
+    // tile_cols tiles per film row, tile_side = tile_size / 8 wave-tiles per tile row, tile_waves = tile_side^2.
+    int32_t tile_size, tile_phase, tile_stride, tile_cols;
+    int32_t tile_side, tile_waves, tiles_owned, pad2;
 };
 
 } // namespace ptamd

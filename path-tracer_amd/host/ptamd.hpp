@@ -260,5 +260,13 @@ inline void Render(Camera& camera, PathTracer& pathTracer, Film& film, uint32_t 
     ptamd_camera c = camera.c();
     check(ptamd_render(pathTracer.Handle(), &c, film.Handle(), sppBegin, sppCount, depth, albedoOnly ? 1 : 0, seed, rect, flags));
 }
+// One rank's interleaved square tiles (tile index % tileStride == tilePhase) in one launch.
+inline void RenderTiles(Camera& camera, PathTracer& pathTracer, Film& film, uint32_t sppBegin, uint32_t sppCount, int depth,
+                        int tileSize, int tilePhase, int tileStride, bool albedoOnly = false, uint32_t seed = 0x5EED, uint32_t flags = 0)
+{
+    ptamd_camera c = camera.c();
+    check(ptamd_render_tiles(pathTracer.Handle(), &c, film.Handle(), sppBegin, sppCount, depth, albedoOnly ? 1 : 0, seed,
+                             tileSize, tilePhase, tileStride, flags));
+}
 
 } // namespace ptamd_host

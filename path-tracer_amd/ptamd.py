@@ -75,7 +75,7 @@ EXPORTS = [
     "ptamd_scene_commit", "ptamd_model_load", "ptamd_model_load_ex", "ptamd_model_desc", "ptamd_model_group_name", "ptamd_model_free",
     "ptamd_film_create", "ptamd_film_create_external", "ptamd_film_destroy", "ptamd_film_resize",
     "ptamd_film_reset", "ptamd_film_size", "ptamd_film_read", "ptamd_film_average",
-    "ptamd_film_resolve_rgba8", "ptamd_film_device_ptrs", "ptamd_render", "ptamd_render_stats",
+    "ptamd_film_resolve_rgba8", "ptamd_film_device_ptrs", "ptamd_render", "ptamd_render_tiles", "ptamd_render_stats",
     "ptamd_camera_rays", "ptamd_closest_hits", "ptamd_traversal_counts",
 ]
 
@@ -137,6 +137,8 @@ def lib():
         L.ptamd_film_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
         L.ptamd_render.argtypes = [vp, C.POINTER(CCamera), vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                    C.c_uint32, C.POINTER(CRect), C.c_uint32]
+        L.ptamd_render_tiles.argtypes = [vp, C.POINTER(CCamera), vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32,
+                                         C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.ptamd_render_stats.argtypes = [C.POINTER(CStats)]
         L.ptamd_camera_rays.argtypes = [C.POINTER(CCamera), C.c_int, C.c_int, vp]
         L.ptamd_closest_hits.argtypes = [vp, vp, C.c_uint32, vp]
@@ -514,11 +516,19 @@ class Film:
 
 
 def Render(camera, pathTracer, film, spp_count, depth, albedoOnly=False, spp_begin=0, seed=0x5EED, rect=None, count=False,
-           russian_roulette=False):
+           russian_roulette=False, tiles=None):
     """spp_count passes of RayTraceParallel in one launch (asynchronous). russian_roulette is an option the
-    reference does not have (off: every path runs to `depth` as in PathTracer.cpp:35-36)."""
+    reference does not have (off: every path runs to `depth` as in PathTracer.cpp:35-36). tiles = (size, phase,
+    stride): only the square tiles phase, phase + stride, ... of the film (one rank's share of a tile split)."""
     r = CRect(*rect) if rect is not None else None
     flags = (FLAG_COUNT if count else 0) | (FLAG_RUSSIAN_ROULETTE if russian_roulette else 0)
+    if tiles is not None:
+        if rect is not None:
+            raise ValueError("rect and tiles exclude each other")
+        size, phase, stride = tiles
+        check(lib().ptamd_render_tiles(pathTracer._h, C.byref(camera.to_c()), film._h, spp_begin, spp_count, depth,
+                                       int(bool(albedoOnly)), seed, int(size), int(phase), int(stride), flags))
+        return
     check(lib().ptamd_render(pathTracer._h, C.byref(camera.to_c()), film._h, spp_begin, spp_count, depth,
                              int(bool(albedoOnly)), seed, C.byref(r) if r is not None else None, flags))
 

@@ -46,9 +46,11 @@ def reduce_film(accum, samples=None, dst=0, all_ranks=False):
             dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
 
 
-def render_sharded(render_rect, width, height, spp_total, mode="spp", rank=None, world=None, tile=32):
+def render_sharded(render_rect, width, height, spp_total, mode="spp", rank=None, world=None, tile=32, render_tiles=None):
     """Drives one rank's share. render_rect(spp_begin, spp_count, rect_or_None) must add the samples to this
-    rank's film. Returns the number of (pixel, sample) pairs this rank rendered."""
+    rank's film. Returns the number of (pixel, sample) pairs this rank rendered. render_tiles(spp_begin,
+    spp_count, tile, phase, stride), when given, renders the rank's interleaved tiles in one launch
+    (ptamd.Render(..., tiles=...)) instead of one launch per tile."""
     rank = dist.get_rank() if rank is None else rank
     world = dist.get_world_size() if world is None else world
     if mode == "spp":
@@ -57,9 +59,12 @@ def render_sharded(render_rect, width, height, spp_total, mode="spp", rank=None,
             render_rect(begin, count, None)
         return width * height * count
     if mode == "tile":
-        done = 0
-        for r in tile_rects(rank, world, width, height, tile):
-            render_rect(0, spp_total, r)
-            done += (r[2] - r[0]) * (r[3] - r[1]) * spp_total
-        return done
+        rects = tile_rects(rank, world, width, height, tile)
+        if render_tiles is not None:
+            if rects:
+                render_tiles(0, spp_total, tile, rank, world)
+        else:
+            for r in rects:
+                render_rect(0, spp_total, r)
+        return sum((r[2] - r[0]) * (r[3] - r[1]) for r in rects) * spp_total
     raise ValueError("mode must be 'spp' or 'tile'")

@@ -95,6 +95,24 @@ def test_config4_4k_film_tile_sharding(gpu):
     assert total == w * h
     assert np.array_equal(tiled.Accum().view(np.uint32), fa.view(np.uint32))
     assert np.array_equal(tiled.Samples(), np.full((h, w), 2, np.uint32))
+    # the same split with one launch per rank: 32-pixel tiles (the default of shard.render_sharded), ragged at the
+    # film's bottom edge (2160 = 67.5 tiles)
+    one = gpu.Film(w, h)
+    total = 0
+    for rank in range(8):
+        total += shard.render_sharded(None, w, h, 2, mode="tile", rank=rank, world=8, tile=32,
+                                      render_tiles=lambda b, c, t, ph, st: gpu.Render(cam, pt, one, c, 3, seed=5, spp_begin=b, tiles=(t, ph, st)))
+    assert total == w * h * 2
+    assert np.array_equal(one.Accum().view(np.uint32), fa.view(np.uint32))
+    assert np.array_equal(one.Samples(), np.full((h, w), 2, np.uint32))
+    # more ranks than tiles, tile larger than the film, bad arguments
+    small = gpu.Film(40, 24)
+    for rank in range(3):
+        gpu.Render(cam, pt, small, 1, 2, tiles=(64, rank, 3))
+    assert np.array_equal(small.Samples(), np.ones((24, 40), np.uint32))
+    for bad in [(12, 0, 1), (32, 2, 2), (32, -1, 2), (32, 0, 0)]:
+        with pytest.raises(Exception):
+            gpu.Render(cam, pt, small, 1, 2, tiles=bad)
 
 
 def test_config2_full_size_properties(gpu, golden):

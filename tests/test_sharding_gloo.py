@@ -71,3 +71,18 @@ def test_slices_partition_the_work():
             for x0, y0, x1, y1 in shard.tile_rects(r, world, 1920 // 8, 1080 // 8, tile=32):
                 seen[y0:y1, x0:x1] += 1
         assert seen.min() == 1 and seen.max() == 1
+
+
+def test_tile_mode_with_a_single_launch_callback():
+    """render_tiles replaces the per-tile loop by one call per rank carrying (tile size, rank, world); the work
+    accounting is the same, and a rank that owns no tile makes no call."""
+    calls = []
+    total = 0
+    for rank in range(3):
+        total += shard.render_sharded(None, 100, 40, 5, mode="tile", rank=rank, world=3, tile=32,
+                                      render_tiles=lambda b, c, t, ph, st: calls.append((b, c, t, ph, st)))
+    assert total == 100 * 40 * 5
+    assert calls == [(0, 5, 32, 0, 3), (0, 5, 32, 1, 3), (0, 5, 32, 2, 3)]
+    calls.clear()
+    assert shard.render_sharded(None, 30, 30, 2, mode="tile", rank=1, world=2, tile=32, render_tiles=lambda *a: calls.append(a)) == 0
+    assert calls == []
