@@ -76,11 +76,87 @@ def measured_traffic(spp, depth):
     import glob
     if (spp, depth) != (1024, 8):
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])  # r1_v9 before r1_v10
     if not files:
         return None
     with open(files[-1]) as f:
         return float(json.load(f)["bytes_per_launch"])
+
+
+def other_config(args, rank, world, ptamd, shard, presets):
+    """The other GPU configurations of BASELINE.json, same timing protocol, no roofline / CPU legs (those are
+    measured on the headline configuration). Sample counts default to a few seconds per step; --spp overrides."""
+    from scenes import gltf_io
+    spp_given = "--spp" in sys.argv
+    if args.config == 3:  # ~1 M triangles with a sky, spp-sharded: every rank renders its own sample range of the frame
+        w, h, depth, spp = 1920, 1080, 8, args.spp if spp_given else 64
+        prim = gltf_io.bumpy_sphere_primitive(500, 1000, radius=1.0, bump=0.06, freq=9)
+        idx = prim["indices"].reshape(-1, 3)
+        data = {"positions": np.ascontiguousarray(prim["positions"][idx].reshape(-1, 9)), "normals": np.ascontiguousarray(prim["normals"][idx].reshape(-1, 9)),
+                "uvs": np.ascontiguousarray(prim["uvs"][idx].reshape(-1, 6)), "group": np.zeros(len(idx), np.int32),
+                "groups": [dict(gltf_io.default_pbr(), base_color_factor=[0.7, 0.6, 0.5, 1.0], metallic_factor=0.0, roughness_factor=0.6, name="m")], "images": []}
+        objs = [{"type": "mesh", "data": data, "pos": (2.775, 2.2, 2.2), "rot": (20.0, 30.0, 0.0), "scale": (2.3, 2.0, 2.1)}]
+        objs += [o for o in presets.cornell_room_boxes()][:1]  # the floor only: the sky lights the rest
+        scene = {"film": (w, h), "camera": presets.default_camera(), "objects": objs}
+        name, mode, rr = "1 M-triangle mesh on a floor under a 64^2 gradient sky cubemap, %dx%d, %d spp per GPU, %d bounces" % (w, h, spp, depth), "spp", False
+    elif args.config == 4:  # 4K mixed spheres + boxes + mesh, tile-sharded: every rank renders its interleaved tiles
+        w, h, depth, spp = 3840, 2160, 8, args.spp if spp_given else 64
+        scene = presets.mixed("tests/golden/blob.glb", w, h, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
+        name, mode, rr = "4K mixed spheres + boxes + 4 k-triangle mesh, %dx%d, %d spp, %d bounces" % (w, h, spp, depth), "tile", False
+    else:  # glass / mirror spheres, 32 bounces with Russian roulette
+        w, h, depth, spp = 1920, 1080, 32, args.spp if spp_given else 256
+        scene = presets.glass_mirror(w, h)
+        name, mode, rr = "glass/mirror spheres, %dx%d, %d spp per GPU, %d bounces, Russian roulette" % (w, h, spp, depth), "spp", True
+    pt, cam = ptamd.build_scene(scene)
+    if args.config == 3:
+        n = 64
+        yy = np.linspace(1.0, 0.0, n, dtype=np.float32)[:, None] * np.ones((1, n), np.float32)
+        def face(level):
+            v = np.clip(level, 0, 1)
+            return np.ascontiguousarray(np.stack([(120 + 100 * v), (150 + 90 * v), (255 * np.ones_like(v)), 255 * np.ones_like(v)], -1).astype(np.uint8))
+        pt.SetSkybox([face(yy), face(yy), face(np.ones((n, n), np.float32)), face(np.zeros((n, n), np.float32)), face(yy), face(yy)], 1.5)
+    accum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    samples = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    film = ptamd.Film(w, h, external=(accum.data_ptr(), samples.data_ptr()))
+
+    def step():
+        accum.zero_(); samples.zero_()
+        if mode == "spp":
+            ptamd.Render(cam, pt, film, spp, depth, spp_begin=rank * spp, russian_roulette=rr)
+        else:
+            ptamd.Render(cam, pt, film, spp, depth, tiles=(32, rank, world))
+        shard.reduce_film(accum, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        per_step = float(w) * h * spp * (world if mode == "spp" else 1)  # tile mode: the film is fixed (strong scaling)
+        value = per_step * args.steps / elapsed * 1e-6
+        print(json.dumps({"metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak" if mode == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": name, "baseline_config": args.config,
+                                     "sharding": "spp-slice per rank" if mode == "spp" else "interleaved 32x32 tiles per rank, one launch (ptamd_render_tiles)"},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -91,6 +167,9 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configuration: 2 (default, the headline) mesh Cornell; 3 1 M-triangle mesh + sky, "
+                         "spp-sharded; 4 4K mixed scene, tile-sharded; 5 glass/mirror, 32 bounces, Russian roulette")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,6 +187,8 @@ def main():
     from scenes import presets
     ptamd.init(local_rank)
     ptamd.set_stream(torch.cuda.current_stream().cuda_stream)  # launches and torch events share one stream
+    if args.config != 2:
+        return other_config(args, rank, world, ptamd, shard, presets)
     scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", W, H)
     pt, cam = ptamd.build_scene(scene)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
