@@ -17,10 +17,24 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def golden_scenes():
+def dragon_field_glb(tmp_path_factory):
+    """The ~1 M-triangle .glb of BASELINE.json's config 3: ten baked instances of tests/golden/chinese_dragon.glb
+    (a byte copy of the reference's assets/models/chinese_dragon.glb), written by scenes/dragon.py (26 MB, 0.2 s)."""
+    from scenes import dragon
+    path = str(tmp_path_factory.mktemp("dragon") / "dragon_field.glb")
+    assert dragon.write_dragon_field(path) == 1_000_000
+    return path
+
+
+@pytest.fixture(scope="session")
+def golden_scenes(dragon_field_glb):
     """name -> (scene dict, depth), the same table tests/golden/make_golden.py rendered with the reference."""
-    from scenes import presets
+    from scenes import dragon, presets
     return {
+        "dragon": ({"film": (96, 72), "camera": {"pos": (28., 12., -60.), "rot": (0., 180., 0.), "fov": 45., "near": .1, "far": 100.},
+                    "objects": [{"type": "mesh", "path": "tests/golden/chinese_dragon.glb", "pos": (0, 0, 0), "rot": (-90., 0, 0),
+                                 "scale": (1, 1.2, 0.8)}]}, 6),
+        "dragon_field": (dragon.config3_scene(dragon_field_glb, 96, 54), 8),
         "sphere_cornell": (presets.sphere_cornell(96, 96), 5),
         "glass_mirror": (presets.glass_mirror(96, 96), 12),
         "box_cornell": (presets.box_cornell(96, 64), 6),

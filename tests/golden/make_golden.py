@@ -1,7 +1,8 @@
 """Generates the golden fixtures in this directory from the reference renderer's own sources
 (oracle/_ref/ref_oracle, built by `make -C oracle ref`; only possible where /root/reference exists).
 
-Run:  python tests/golden/make_golden.py
+Run:  python tests/golden/make_golden.py            (every scene + the film vectors)
+      python tests/golden/make_golden.py dragon dragon_field   (only the named scenes)
 Writes small .npz files (inputs + expected outputs) and the .glb inputs the reference loaded.
 Nothing of the reference's source text is stored: only scene parameters and output buffers.
 """
@@ -14,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle as po  # noqa: E402
-from scenes import gltf_io, presets  # noqa: E402
+from scenes import dragon, gltf_io, presets  # noqa: E402
 
 
 def lum(a):
@@ -62,6 +63,15 @@ def write_textured_glb(path):
     gltf_io.write_glb(path, [p0, p1, p2], mats, images)
 
 
+def dragon_scenes(field_glb):
+    """The reference's own 100 000-triangle model (tests/golden/chinese_dragon.glb is a byte copy of its
+    assets/models/chinese_dragon.glb) alone under the constant background, and the ten-instance field derived from
+    it (scenes/dragon.py, ~1 M triangles, regenerated wherever it is needed) in the closed room."""
+    single = {"film": (96, 72), "camera": {"pos": (28., 12., -60.), "rot": (0., 180., 0.), "fov": 45., "near": .1, "far": 100.},
+              "objects": [{"type": "mesh", "path": "tests/golden/chinese_dragon.glb", "pos": (0, 0, 0), "rot": (-90., 0, 0), "scale": (1, 1.2, 0.8)}]}
+    return {"dragon": (single, 6), "dragon_field": (dragon.config3_scene(field_glb, 96, 54), 8)}
+
+
 def golden_scenes():
     """name -> (scene dict, depth for the stochastic render)."""
     cm = os.path.join(HERE, "cornell_mesh.glb")
@@ -92,7 +102,14 @@ def golden_scenes():
 def main():
     assert po.have_ref(), "build oracle/_ref first: make -C oracle ref"
     os.chdir(ROOT)  # mesh paths in the scenes are relative to the repo root
-    for name, (scene, depth) in golden_scenes().items():
+    only = sys.argv[1:]
+    import tempfile
+    field = os.path.join(tempfile.mkdtemp(prefix="ptgold_"), "dragon_field.glb")
+    dragon.write_dragon_field(field)
+    scenes = dict(golden_scenes() if not only or any(n not in ("dragon", "dragon_field") for n in only) else {}, **dragon_scenes(field))
+    for name, (scene, depth) in scenes.items():
+        if only and name not in only:
+            continue
         rays = po.ref_rays(scene)
         hits = po.ref_hits(scene)
         alb, alb_s, alb_rgba, _ = po.ref_render(scene, 1, 10, True, threads=4, tasks=16)
@@ -108,6 +125,8 @@ def main():
                             self_rmse=self_rmse, mean_lum_a=float(lum(A1).mean()), mean_lum_b=float(lum(A2).mean()),
                             rgba_a=rgba1)
         print(name, "self_rmse", self_rmse, "lum", float(lum(A1).mean()), float(lum(A2).mean()))
+    if only:
+        return
     # Film known-answer vectors: AddSample clamp + the four resolve variants
     rng = np.random.default_rng(7)
     vals = np.concatenate([rng.random((200, 3)) * np.array([0.02, 1.0, 30.0])[rng.integers(0, 3, (200, 1))],
