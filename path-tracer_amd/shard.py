@@ -35,7 +35,7 @@ def tile_rects(rank, world, width, height, tile=32):
 def reduce_film(accum, samples=None, dst=0, all_ranks=False):
     """Sums the per-rank accumulation buffers (and optionally the per-pixel sample counts) onto `dst`
     (or onto every rank). One collective per tensor; tensors are reduced in place."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():  # a single process without a process group; a group of one still runs the collective
         return
     for t in (accum, samples):
         if t is None:
