@@ -204,6 +204,14 @@ int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_
 int ptamd_render_tiles(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
                        int depth, int albedo_only, uint32_t seed, int tile_size, int tile_phase, int tile_stride, uint32_t flags);
 int ptamd_render_stats(ptamd_stats* out); /* synchronises */
+/* No counterpart in the reference. ptamd_render with PTAMD_FLAG_COUNT for callers that cannot allocate (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the launch tallies into a statically allocated
+ * device array of the library (the 10 counters of ptamd_stats, 80 bytes per GPU) and the totals are then copied, on the
+ * library stream, to d_stats, a DEVICE pointer to one ptamd_stats that the caller owns. The call allocates and frees
+ * nothing and does not synchronise; film and sample values are those of ptamd_render. All calls on one GPU share the
+ * array (it is cleared at the start of each call): calls that overlap on one GPU race. */
+int ptamd_render_counted_noalloc(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
+                                 int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags, ptamd_stats* d_stats);
 
 /* ---- probes used by the parity tests ------------------------------------------------------- */
 /* Camera::GetRay (Camera.cpp:38-64) for every pixel: out[(y*w+x)*6] = origin xyz, direction xyz (host). */

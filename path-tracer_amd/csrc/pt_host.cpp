@@ -24,6 +24,7 @@ hipError_t launch_closest_hits(const DScene& sc, const float* d_rays, uint32_t n
 hipError_t launch_average(const float* accum, const uint32_t* samples, int n, float* avg, hipStream_t stream);
 hipError_t launch_resolve(const float* accum, const uint32_t* samples, int n, int tonemap, int colourspace, uint32_t* rgba, hipStream_t stream);
 int max_stack_depth();
+hipError_t scratch_counters(int device, unsigned long long** out);
 } // namespace ptamd
 
 using namespace ptamd;
@@ -37,6 +38,7 @@ bool g_initialised = false;
 int g_device = -1;
 constexpr int kNumCounters = 10;
 unsigned long long* g_counters = nullptr; // device, kNumCounters x u64 (the fields of ptamd_stats)
+unsigned long long* g_static_counters = nullptr; // the same, in the library's static device array (no allocation behind it)
 
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
 
@@ -240,6 +242,8 @@ int ptamd_init(int device)
     PT_HIP(hipSetDevice(device));
     if (!g_own_stream) { PT_HIP(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking)); g_stream = g_own_stream; }
     if (!g_counters) PT_HIP(hipMalloc(reinterpret_cast<void**>(&g_counters), kNumCounters * sizeof(unsigned long long)));
+    // the statically allocated counters of ptamd_render_counted_noalloc: their address on this device, resolved once here
+    PT_HIP(scratch_counters(device, &g_static_counters));
     g_initialised = true; g_device = device;
     return PTAMD_OK;
 }
@@ -726,9 +730,10 @@ int ptamd_film_device_ptrs(ptamd_film* f, void** a, void** s)
 }
 
 // ------------------------------------------------------------------------------- render
+// counters: where a PTAMD_FLAG_COUNT launch tallies (kNumCounters x u64 of device memory, cleared here first)
 static int render_impl(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
                        int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags,
-                       int tile_size, int tile_phase, int tile_stride)
+                       int tile_size, int tile_phase, int tile_stride, unsigned long long* counters)
 {
     if (!s || !cam || !f) return fail(PTAMD_ERR_ARG, "null argument");
     if (int rc = need_init()) return rc;
@@ -742,8 +747,8 @@ static int render_impl(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, u
     rp.x0 = rect ? std::max(0, rect->x0) : 0; rp.y0 = rect ? std::max(0, rect->y0) : 0;
     rp.x1 = rect ? std::min(f->w, rect->x1) : f->w; rp.y1 = rect ? std::min(f->h, rect->y1) : f->h;
     if (flags & PTAMD_FLAG_COUNT) {
-        PT_HIP(hipMemsetAsync(g_counters, 0, kNumCounters * sizeof(unsigned long long), g_stream));
-        rp.counters = g_counters;
+        PT_HIP(hipMemsetAsync(counters, 0, kNumCounters * sizeof(unsigned long long), g_stream));
+        rp.counters = counters;
     }
     if (rp.x1 <= rp.x0 || rp.y1 <= rp.y0 || spp_count == 0) return PTAMD_OK;
     rp.spp_begin = spp_begin; rp.spp_count = spp_count;
@@ -767,14 +772,24 @@ static int render_impl(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, u
 int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
                  int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags)
 {
-    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, rect, flags, 0, 0, 0);
+    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, rect, flags, 0, 0, 0, g_counters);
+}
+int ptamd_render_counted_noalloc(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
+                                 int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags, ptamd_stats* d_stats)
+{
+    if (!d_stats) return fail(PTAMD_ERR_ARG, "null device pointer for the statistics");
+    if (int rc = need_init()) return rc;
+    static_assert(sizeof(ptamd_stats) == kNumCounters * sizeof(unsigned long long), "ptamd_stats is the counter array");
+    if (int rc = render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, rect, flags | PTAMD_FLAG_COUNT, 0, 0, 0, g_static_counters)) return rc;
+    PT_HIP(hipMemcpyAsync(d_stats, g_static_counters, sizeof(ptamd_stats), hipMemcpyDeviceToDevice, g_stream));
+    return PTAMD_OK;
 }
 int ptamd_render_tiles(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
                        int depth, int albedo_only, uint32_t seed, int tile_size, int tile_phase, int tile_stride, uint32_t flags)
 {
     if (tile_size < 8 || tile_size % 8 != 0 || tile_size > 4096) return fail(PTAMD_ERR_ARG, "tile_size must be a multiple of 8 in [8, 4096]");
     if (tile_stride < 1 || tile_phase < 0 || tile_phase >= tile_stride) return fail(PTAMD_ERR_ARG, "need 0 <= tile_phase < tile_stride");
-    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, nullptr, flags, tile_size, tile_phase, tile_stride);
+    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, nullptr, flags, tile_size, tile_phase, tile_stride, g_counters);
 }
 int ptamd_render_stats(ptamd_stats* out)
 {

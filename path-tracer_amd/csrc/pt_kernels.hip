@@ -341,4 +341,26 @@ hipError_t launch_resolve(const float* accum, const uint32_t* samples, int n, in
 }
 int max_stack_depth() { return kStackDepth; }
 
+// Counters of ptamd_render_counted_noalloc: a counting launch tallies into this array instead of into memory that the
+// library allocated, so that entry point calls no allocator at all. 80 bytes per GPU, held until the process ends.
+// Every call on a GPU shares the array (calls that overlap on one GPU race) and clears it before its launch. In host
+// code the array's name is only a handle for the symbol lookup below; kernels, memsets and copies take the address
+// that the lookup returned.
+static __device__ __align__(256) unsigned long long scratch[kNumCounters];
+constexpr int kMaxDevices = 64;
+static unsigned long long* g_scratch_address[kMaxDevices] = {};
+// Address of `scratch` on `device`, which must be the current device (each GPU holds its own copy at its own address).
+hipError_t scratch_counters(int device, unsigned long long** out)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_scratch_address[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_address[device] = static_cast<unsigned long long*>(p);
+    }
+    *out = g_scratch_address[device];
+    return hipSuccess;
+}
+
 } // namespace ptamd

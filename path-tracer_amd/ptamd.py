@@ -75,7 +75,7 @@ EXPORTS = [
     "ptamd_scene_commit", "ptamd_model_load", "ptamd_model_load_ex", "ptamd_model_desc", "ptamd_model_group_name", "ptamd_model_free",
     "ptamd_film_create", "ptamd_film_create_external", "ptamd_film_destroy", "ptamd_film_resize",
     "ptamd_film_reset", "ptamd_film_size", "ptamd_film_read", "ptamd_film_average",
-    "ptamd_film_resolve_rgba8", "ptamd_film_device_ptrs", "ptamd_render", "ptamd_render_tiles", "ptamd_render_stats",
+    "ptamd_film_resolve_rgba8", "ptamd_film_device_ptrs", "ptamd_render", "ptamd_render_tiles", "ptamd_render_stats", "ptamd_render_counted_noalloc",
     "ptamd_camera_rays", "ptamd_closest_hits", "ptamd_traversal_counts",
 ]
 
@@ -140,6 +140,8 @@ def lib():
         L.ptamd_render_tiles.argtypes = [vp, C.POINTER(CCamera), vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32,
                                          C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.ptamd_render_stats.argtypes = [C.POINTER(CStats)]
+        L.ptamd_render_counted_noalloc.argtypes = [vp, C.POINTER(CCamera), vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                                   C.c_uint32, C.POINTER(CRect), C.c_uint32, vp]
         L.ptamd_camera_rays.argtypes = [C.POINTER(CCamera), C.c_int, C.c_int, vp]
         L.ptamd_closest_hits.argtypes = [vp, vp, C.c_uint32, vp]
         L.ptamd_traversal_counts.argtypes = [vp, vp, C.c_uint32, vp, vp]
