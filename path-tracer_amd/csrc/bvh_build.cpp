@@ -283,3 +283,129 @@ BvhResult build_bvh(const float* P, const int32_t* group, uint32_t n, int max_de
 }
 
 } // namespace ptamd
+
+// ------------------------------------------------------------------------------------------------ eight-wide collapse
+namespace ptamd {
+namespace {
+
+struct WideItem { int32_t ref; float lo[3], hi[3]; };
+
+float item_area(const WideItem& it)
+{
+    const float dx = it.hi[0] - it.lo[0], dy = it.hi[1] - it.lo[1], dz = it.hi[2] - it.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+void children_of(const DNode& n, WideItem& l, WideItem& r)
+{
+    l.ref = n.left; r.ref = n.right;
+    l.lo[0] = n.lmin[0]; l.lo[1] = n.lmin[1]; l.lo[2] = n.lmin[2]; l.hi[0] = n.lmax0; l.hi[1] = n.lmax12[0]; l.hi[2] = n.lmax12[1];
+    r.lo[0] = n.rmin01[0]; r.lo[1] = n.rmin01[1]; r.lo[2] = n.rmin2; r.hi[0] = n.rmax[0]; r.hi[1] = n.rmax[1]; r.hi[2] = n.rmax[2];
+}
+
+} // namespace
+
+void build_wide(BvhResult& res)
+{
+    res.wide.clear(); res.wide_order.clear(); res.wide_depth = 0;
+    if (res.root < 0 || res.nodes.empty()) return;
+    struct Pending { int32_t binary; uint32_t wide; int level; };
+    std::vector<Pending> queue;
+    res.wide.emplace_back();
+    queue.push_back({ res.root, 0u, 1 });
+    res.wide_order.reserve(res.order.size());
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+        const Pending pe = queue[qi];
+        res.wide_depth = std::max(res.wide_depth, pe.level);
+        // Collapse: start from the two children of the binary node and keep opening the inner child with the largest
+        // surface area until there are eight children or only leaves.
+        WideItem items[8]; int n = 2;
+        children_of(res.nodes[(size_t)pe.binary], items[0], items[1]);
+        while (n < 8) {
+            int best = -1; float bestArea = -1.f;
+            for (int i = 0; i < n; ++i) if (items[i].ref >= 0 && item_area(items[i]) > bestArea) { bestArea = item_area(items[i]); best = i; }
+            if (best < 0) break;
+            WideItem l, r;
+            children_of(res.nodes[(size_t)items[best].ref], l, r);
+            items[best] = l; items[n++] = r;
+        }
+        // Node frame: origin = lower corner of all children, pitch 2^e per axis with 255 * 2^e >= extent.
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) { lo[k] = std::numeric_limits<float>::max(); hi[k] = -std::numeric_limits<float>::max(); }
+        for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) {
+            if (items[i].lo[k] <= items[i].hi[k]) { lo[k] = std::min(lo[k], items[i].lo[k]); hi[k] = std::max(hi[k], items[i].hi[k]); }
+        }
+        DWideNode w; std::memset(&w, 0, sizeof w);
+        int e[3]; double pitch[3];
+        for (int k = 0; k < 3; ++k) {
+            if (!(lo[k] <= hi[k])) { lo[k] = hi[k] = 0.f; } // only empty boxes (inert triangles)
+            w.origin[k] = lo[k];
+            const double ext = (double)hi[k] - (double)lo[k];
+            int ek = -100;
+            if (ext > 0.0) { ek = (int)std::ceil(std::log2(ext / 255.0)); while (std::ldexp(255.0, ek) < ext) ++ek; }
+            ek = std::max(-126, std::min(126, ek));
+            e[k] = ek; pitch[k] = std::ldexp(1.0, ek);
+        }
+        w.ex = (uint8_t)(e[0] + 127); w.ey = (uint8_t)(e[1] + 127); w.ez = (uint8_t)(e[2] + 127);
+        // Slot assignment: slot bits say on which side of the node centre a child should lie (bit k set = upper side of
+        // axis k), so that slot ^ (octant of the ray direction) orders the children roughly front to back. Greedy: the
+        // best (child, slot) pair first.
+        int slotOf[8]; bool slotUsed[8] = { false }, childDone[8] = { false };
+        float centre[3]; for (int k = 0; k < 3; ++k) centre[k] = 0.5f * (lo[k] + hi[k]);
+        for (int round = 0; round < n; ++round) {
+            int bc = -1, bs = -1; float bestScore = -std::numeric_limits<float>::max();
+            for (int c = 0; c < n; ++c) {
+                if (childDone[c]) continue;
+                for (int s = 0; s < 8; ++s) {
+                    if (slotUsed[s]) continue;
+                    float score = 0.f;
+                    for (int k = 0; k < 3; ++k) {
+                        const float d = 0.5f * (items[c].lo[k] + items[c].hi[k]) - centre[k];
+                        score += ((s >> k) & 1) ? d : -d;
+                    }
+                    if (score > bestScore) { bestScore = score; bc = c; bs = s; }
+                }
+            }
+            slotOf[bc] = bs; slotUsed[bs] = true; childDone[bc] = true;
+        }
+        int childAt[8]; for (int s = 0; s < 8; ++s) childAt[s] = -1;
+        for (int c = 0; c < n; ++c) childAt[slotOf[c]] = c;
+        w.child_base = (uint32_t)res.wide.size();
+        w.tri_base = (uint32_t)res.wide_order.size();
+        for (int s = 0; s < 8; ++s) {
+            uint8_t* q[6] = { &w.qlo_x[s], &w.qlo_y[s], &w.qlo_z[s], &w.qhi_x[s], &w.qhi_y[s], &w.qhi_z[s] };
+            const int c = childAt[s];
+            if (c < 0 || !(items[c].lo[0] <= items[c].hi[0])) { // empty slot, or a child that holds only inert triangles
+                for (int k = 0; k < 3; ++k) { *q[k] = 255; *q[3 + k] = 0; }
+                if (c < 0) continue;
+            } else {
+                for (int k = 0; k < 3; ++k) {
+                    double a = std::floor(((double)items[c].lo[k] - (double)w.origin[k]) / pitch[k]);
+                    double b = std::ceil(((double)items[c].hi[k] - (double)w.origin[k]) / pitch[k]);
+                    a = std::max(0.0, std::min(255.0, a)); b = std::max(0.0, std::min(255.0, b));
+                    // outward in the arithmetic of the kernels as well: origin + q * pitch evaluated in float
+                    while (a > 0.0 && (float)((double)w.origin[k] + a * pitch[k]) > items[c].lo[k]) a -= 1.0;
+                    while (b < 255.0 && (float)((double)w.origin[k] + b * pitch[k]) < items[c].hi[k]) b += 1.0;
+                    *q[k] = (uint8_t)a; *q[3 + k] = (uint8_t)b;
+                }
+            }
+            if (items[c].ref >= 0) {
+                w.imask |= (uint8_t)(1u << s);
+                queue.push_back({ items[c].ref, (uint32_t)res.wide.size(), pe.level + 1 });
+                res.wide.emplace_back();
+            } else {
+                const uint32_t code = ~(uint32_t)items[c].ref;
+                const uint32_t first = code >> 6, mask = (code >> 2) & 15u, prims = (code & 3u) + 1u;
+                if (prims > 2u) { res.wide.clear(); res.wide_order.clear(); res.wide_depth = 0; return; } // the slot byte holds leaves of 1 or 2 primitives
+                uint32_t slots = 0;
+                for (uint32_t i = 0; i < prims; ++i) slots += ((mask >> i) & 1u) ? 2u : 1u;
+                const uint32_t rel = (uint32_t)res.wide_order.size() - w.tri_base;
+                // at most 8 leaf slots of at most 2 primitives (4 triangle slots) each: rel <= 28
+                w.meta[s] = (uint8_t)(rel | ((prims - 1u) << 5) | ((mask & 3u) << 6));
+                for (uint32_t i = 0; i < slots; ++i) res.wide_order.push_back(res.order[first + i]);
+            }
+        }
+        res.wide[pe.wide] = w;
+    }
+}
+
+} // namespace ptamd

@@ -42,10 +42,13 @@ struct JValue {
 
 struct JParser {
     const char* p; const char* end;
+    int depth = 0; // nesting of the value being parsed: bounded, so that a file of brackets cannot exhaust the stack
     [[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string("glTF JSON parse error: ") + what); }
     void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p; }
     JPtr parse()
     {
+        struct Nest { int& d; explicit Nest(int& x) : d(x) { ++d; } ~Nest() { --d; } } nest(depth);
+        if (depth > 256) fail("nesting deeper than 256 levels");
         ws();
         if (p >= end) fail("unexpected end");
         auto v = std::make_shared<JValue>();
@@ -177,7 +180,8 @@ void decode_png_rgba(const uint8_t* data, size_t size, int& w, int& h, std::vect
         const uint8_t* tag = data + pos + 4;
         const uint8_t* body = data + pos + 8;
         if (pos + 12 + n > size) throw std::runtime_error("image: truncated PNG");
-        if (!std::memcmp(tag, "IHDR", 4)) { w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        if (!std::memcmp(tag, "IHDR", 4)) { if (n != 13) throw std::runtime_error("image: bad PNG header");
+                                           w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
         else if (!std::memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), body, body + n);
         else if (!std::memcmp(tag, "PLTE", 4)) plte.assign(body, body + n);
         else if (!std::memcmp(tag, "tRNS", 4)) trns.assign(body, body + n);
@@ -249,23 +253,38 @@ const JValue& at(const JValue* arr, size_t i, const char* what)
     if (!arr || arr->type != JValue::Array || i >= arr->arr.size()) throw std::runtime_error(std::string("glTF: bad index into ") + what);
     return *arr->arr[i];
 }
-View accessor_view(const Doc& d, int index)
+// Every index, count, offset and stride of the file goes through here before it takes part in pointer arithmetic: a
+// finite, non-negative whole number of at most 2^48 (absent: the default); anything else is refused, as tinygltf
+// refuses it for the reference.
+size_t file_uint(const JValue* v, const char* what, size_t dflt = 0)
 {
-    const JValue& acc = at(d.root->get("accessors"), (size_t)index, "accessors");
+    if (!v) return dflt;
+    if (v->type != JValue::Number || !(v->num >= 0.0) || !(v->num <= 281474976710656.0) || v->num != std::floor(v->num))
+        throw std::runtime_error(std::string("glTF: ") + what + " is not a valid unsigned integer");
+    return (size_t)v->num;
+}
+View accessor_view(const Doc& d, const JValue* indexValue)
+{
+    const JValue& acc = at(d.root->get("accessors"), file_uint(indexValue, "accessor index"), "accessors");
     const JValue* bvIdx = acc.get("bufferView");
     if (!bvIdx) throw std::runtime_error("glTF: accessor without bufferView is not supported");
-    const JValue& bv = at(d.root->get("bufferViews"), (size_t)bvIdx->num, "bufferViews");
-    size_t buf = (size_t)(bv.get("buffer") ? bv.get("buffer")->num : 0);
+    const JValue& bv = at(d.root->get("bufferViews"), file_uint(bvIdx, "bufferView index"), "bufferViews");
+    const size_t buf = file_uint(bv.get("buffer"), "buffer index");
     if (buf >= d.buffers.size()) throw std::runtime_error("glTF: bad buffer index");
     View v;
-    v.comp = (int)(acc.get("componentType") ? acc.get("componentType")->num : 0);
-    v.type = acc.get("type") ? acc.get("type")->str : "";
-    v.count = (size_t)(acc.get("count") ? acc.get("count")->num : 0);
-    size_t off = (size_t)(bv.get("byteOffset") ? bv.get("byteOffset")->num : 0) + (size_t)(acc.get("byteOffset") ? acc.get("byteOffset")->num : 0);
-    size_t elem = (size_t)comp_size(v.comp) * (size_t)type_count(v.type);
-    size_t bs = (size_t)(bv.get("byteStride") ? bv.get("byteStride")->num : 0);
+    v.comp = (int)file_uint(acc.get("componentType"), "componentType");
+    v.type = (acc.get("type") && acc.get("type")->type == JValue::String) ? acc.get("type")->str : "";
+    v.count = file_uint(acc.get("count"), "accessor count");
+    const size_t off = file_uint(bv.get("byteOffset"), "byteOffset") + file_uint(acc.get("byteOffset"), "byteOffset");
+    const size_t elem = (size_t)comp_size(v.comp) * (size_t)type_count(v.type);
+    const size_t bs = file_uint(bv.get("byteStride"), "byteStride");
     v.stride = bs ? bs : elem;
-    if (v.count && off + v.stride * (v.count - 1) + elem > d.buffers[buf].size()) throw std::runtime_error("glTF: accessor out of buffer range");
+    // range check without overflow: the first element fits, and count - 1 further strides fit behind it
+    const size_t size = d.buffers[buf].size();
+    if (v.count) {
+        if (elem == 0 || off > size || elem > size - off) throw std::runtime_error("glTF: accessor out of buffer range");
+        if (v.count - 1 > 0 && (v.stride == 0 ? false : (v.count - 1) > (size - off - elem) / v.stride)) throw std::runtime_error("glTF: accessor out of buffer range");
+    }
     v.ptr = d.buffers[buf].data() + off;
     return v;
 }
@@ -275,9 +294,12 @@ int texture_source(const Doc& d, const JValue* texInfo)
     if (!texInfo) return -1;
     const JValue* idx = texInfo->get("index");
     if (!idx || !idx->is_number() || idx->num < 0) return -1;
-    const JValue& t = at(d.root->get("textures"), (size_t)idx->num, "textures");
+    const JValue& t = at(d.root->get("textures"), file_uint(idx, "texture index"), "textures");
     const JValue* src = t.get("source");
-    return src && src->is_number() ? (int)src->num : -1;
+    if (!src || !src->is_number() || src->num < 0) return -1;
+    const size_t i = file_uint(src, "texture source");
+    if (i > 0x7fffffffu) throw std::runtime_error("glTF: texture source is not a valid image index");
+    return (int)i;
 }
 
 } // namespace
@@ -343,11 +365,11 @@ static void load_any(const std::string& path, Model& out, uint32_t flags)
         for (const auto& im : imgs->arr) {
             std::vector<uint8_t> raw;
             if (const JValue* bvI = im->get("bufferView")) {
-                const JValue& bv = at(d.root->get("bufferViews"), (size_t)bvI->num, "bufferViews");
-                size_t buf = (size_t)(bv.get("buffer") ? bv.get("buffer")->num : 0);
-                size_t off = (size_t)(bv.get("byteOffset") ? bv.get("byteOffset")->num : 0);
-                size_t len = (size_t)(bv.get("byteLength") ? bv.get("byteLength")->num : 0);
-                if (buf >= d.buffers.size() || off + len > d.buffers[buf].size()) throw std::runtime_error("glTF: image bufferView out of range");
+                const JValue& bv = at(d.root->get("bufferViews"), file_uint(bvI, "bufferView index"), "bufferViews");
+                const size_t buf = file_uint(bv.get("buffer"), "buffer index");
+                const size_t off = file_uint(bv.get("byteOffset"), "byteOffset");
+                const size_t len = file_uint(bv.get("byteLength"), "byteLength");
+                if (buf >= d.buffers.size() || off > d.buffers[buf].size() || len > d.buffers[buf].size() - off) throw std::runtime_error("glTF: image bufferView out of range");
                 raw.assign(d.buffers[buf].begin() + (long)off, d.buffers[buf].begin() + (long)(off + len));
             } else if (const JValue* uri = im->get("uri")) {
                 if (uri->str.rfind("data:", 0) == 0) raw = base64_decode(uri->str, uri->str.find(',') + 1);
@@ -386,25 +408,25 @@ static void load_any(const std::string& path, Model& out, uint32_t flags)
         if (!prims) return;
         for (const auto& prim : prims->arr) {
             const JValue* mode = prim->get("mode");
-            if (mode && (int)mode->num != 4) throw std::runtime_error("Only TRIANGLES are supported");
+            if (mode && !(mode->is_number() && mode->num == 4.0)) throw std::runtime_error("Only TRIANGLES are supported");
             const JValue* attrs = prim->get("attributes");
             if (!attrs || !attrs->get("POSITION")) throw std::runtime_error("Missing POSITION");
-            View pos = accessor_view(d, (int)attrs->get("POSITION")->num);
+            View pos = accessor_view(d, attrs->get("POSITION"));
             if (pos.type != "VEC3" || pos.comp != 5126) throw std::runtime_error("POSITION must be float vec3");
             View nrm{}; bool hasN = false;
-            if (const JValue* a = attrs->get("NORMAL")) { nrm = accessor_view(d, (int)a->num); hasN = nrm.type == "VEC3" && nrm.comp == 5126; }
+            if (const JValue* a = attrs->get("NORMAL")) { nrm = accessor_view(d, a); hasN = nrm.type == "VEC3" && nrm.comp == 5126; }
             View uv{}; bool hasT = false;
-            if (const JValue* a = attrs->get("TEXCOORD_0")) { uv = accessor_view(d, (int)a->num); hasT = uv.type == "VEC2" && uv.comp == 5126; }
+            if (const JValue* a = attrs->get("TEXCOORD_0")) { uv = accessor_view(d, a); hasT = uv.type == "VEC2" && uv.comp == 5126; }
             const JValue* indices = prim->get("indices");
             if (!indices || indices->num < 0) throw std::runtime_error("Indexed geometry required");
-            View iv = accessor_view(d, (int)indices->num);
+            View iv = accessor_view(d, indices);
             if (iv.type != "SCALAR") throw std::runtime_error("indices accessor must be SCALAR");
             if (iv.comp != 5121 && iv.comp != 5123 && iv.comp != 5125) throw std::runtime_error("Unsupported index type");
 
             int groupIndex = -1;
             const JValue* matI = prim->get("material");
             if (matI && matI->is_number() && matI->num >= 0) { // ModelLoader.h:263-362
-                const JValue& mat = at(mats, (size_t)matI->num, "materials");
+                const JValue& mat = at(mats, file_uint(matI, "material index"), "materials");
                 std::string name = mat.get("name") ? mat.get("name")->str : std::string();
                 for (size_t g = 0; g < out.group_names.size(); ++g) if (out.group_names[g] == name) { groupIndex = (int)g; break; }
                 if (groupIndex < 0) {
@@ -441,8 +463,7 @@ static void load_any(const std::string& path, Model& out, uint32_t flags)
                             const JValue* texs = d.root->get("textures");
                             if (ti && ti->is_number() && ti->is_int && ti->num >= 0 && texs && ti->num < (double)texs->arr.size()) {
                                 const JValue* src = texs->arr[(size_t)ti->num]->get("source");
-                                int img = src ? (int)src->num : -1;
-                                if (img >= 0 && img < (int)out.images.size()) g.transmission_tex = img;
+                                if (src && src->is_number() && src->num >= 0 && src->num < (double)out.images.size()) g.transmission_tex = (int)src->num;
                             }
                         }
                     }
@@ -522,19 +543,19 @@ static void load_any(const std::string& path, Model& out, uint32_t flags)
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 4; ++c)
                 W[4 * r + c] = P[4 * r] * L[c] + P[4 * r + 1] * L[4 + c] + P[4 * r + 2] * L[8 + c] + (c == 3 ? P[4 * r + 3] : 0.0);
-        if (const JValue* m = n.get("mesh")) if (m->is_number() && m->num >= 0) emit_mesh(at(meshes, (size_t)m->num, "meshes"), W);
-        if (const JValue* ch = n.get("children")) for (const auto& c : ch->arr) visit((size_t)c->num, W);
+        if (const JValue* m = n.get("mesh")) if (m->is_number() && m->num >= 0) emit_mesh(at(meshes, file_uint(m, "mesh index"), "meshes"), W);
+        if (const JValue* ch = n.get("children")) for (const auto& c : ch->arr) visit(file_uint(c.get(), "node index"), W);
         onPath.pop_back();
     };
     const double I[12] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
     const JValue* scenes = d.root->get("scenes");
     if (scenes && !scenes->arr.empty()) {
-        size_t si = (d.root->get("scene") && d.root->get("scene")->is_number()) ? (size_t)d.root->get("scene")->num : 0;
+        size_t si = (d.root->get("scene") && d.root->get("scene")->is_number()) ? file_uint(d.root->get("scene"), "scene index") : 0;
         const JValue& sc = at(scenes, si, "scenes");
-        if (const JValue* roots = sc.get("nodes")) for (const auto& r : roots->arr) visit((size_t)r->num, I);
+        if (const JValue* roots = sc.get("nodes")) for (const auto& r : roots->arr) visit(file_uint(r.get(), "node index"), I);
     } else { // no scene: every node that is nobody's child is a root
         std::vector<char> isChild(nodes->arr.size(), 0);
-        for (const auto& n : nodes->arr) if (const JValue* ch = n->get("children")) for (const auto& c : ch->arr) if ((size_t)c->num < isChild.size()) isChild[(size_t)c->num] = 1;
+        for (const auto& n : nodes->arr) if (const JValue* ch = n->get("children")) for (const auto& c : ch->arr) { const size_t ci = file_uint(c.get(), "node index"); if (ci < isChild.size()) isChild[ci] = 1; }
         for (size_t i = 0; i < nodes->arr.size(); ++i) if (!isChild[i]) visit(i, I);
     }
 }

@@ -461,6 +461,164 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
     return (int)(uint32_t)best - 1;
 }
 
+// ---------------------------------------------------------------- eight-wide traversal (meshes read from global memory)
+//
+// Walks DWideNode trees (pt_types.h). One loop trip = one node visit: five 16-byte reads bring the frame and the
+// eight quantised child boxes, the slab tests run on bytes converted in registers (v_cvt_f32_ubyteN), and the hits
+// come out as two 8-bit masks in traversal order (bit i = slot i ^ octant of the ray): leaf children, whose
+// primitives are tested at once, and inner children, which stay in the current group {child_base, hits << 8 | imask}.
+// The next node is the lowest set bit of the current group; a group that still has bits when a new node is opened goes
+// on the per-lane LDS stack (two 4-byte rows per entry), so the stack holds at most one entry per tree level. Pending
+// children carry no distance: one that has fallen behind the closest hit costs its visit, in which all eight boxes fail.
+PT_DEV uint32_t permute_slots16(uint32_t m, uint32_t oct) // bit (s ^ oct) of each byte of the result = bit s of that byte of m
+{
+    if (oct & 1u) m = ((m & 0x5555u) << 1) | ((m >> 1) & 0x5555u);
+    if (oct & 2u) m = ((m & 0x3333u) << 2) | ((m >> 2) & 0x3333u);
+    if (oct & 4u) m = ((m & 0x0f0fu) << 4) | ((m >> 4) & 0x0f0fu);
+    return m;
+}
+template <int S> PT_DEV float byte_of(uint32_t lo, uint32_t hi) // byte S (0..7) of the 8-byte pair as a float
+{
+    const uint32_t w = S < 4 ? lo : hi;
+    return (float)((w >> (8 * (S & 3))) & 255u);
+}
+template <int S>
+PT_DEV uint32_t wide_slab(uint32_t nx0, uint32_t nx1, uint32_t ny0, uint32_t ny1, uint32_t nz0, uint32_t nz1,
+                          uint32_t fx0, uint32_t fx1, uint32_t fy0, uint32_t fy1, uint32_t fz0, uint32_t fz1,
+                          f3 sc, f3 of, float bound)
+{
+    const float tn = fmaxf(fmaxf(fmaf(byte_of<S>(nx0, nx1), sc.x, of.x), fmaf(byte_of<S>(ny0, ny1), sc.y, of.y)), fmaxf(fmaf(byte_of<S>(nz0, nz1), sc.z, of.z), 0.0f));
+    const float tf = fminf(fminf(fmaf(byte_of<S>(fx0, fx1), sc.x, of.x), fmaf(byte_of<S>(fy0, fy1), sc.y, of.y)), fminf(fmaf(byte_of<S>(fz0, fz1), sc.z, of.z), bound));
+    return tf >= tn ? (1u << S) : 0u;
+}
+
+// Work sharing as in mesh_traverse_coop: a lane works on a task = (some lane's ray, a group of pending children);
+// hits are published with an atomic minimum on the owner's 64-bit word, which is also the pruning bound that a task
+// re-reads when it pops; an idle lane takes over the oldest stack entry (a whole group) of a lane that has one. A
+// loop trip is wave-uniform: every lane that can opens one node, or every lane that holds hit leaf children tests
+// the primitives of one of them, whichever group is larger. `valid`: this lane has a ray of its own (all lanes of
+// the wave make the call). Returns the closest triangle slot (mesh-relative, or -1) and its distance in closestT.
+template <int BLOCK, bool COUNT>
+PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 o, f3 d, float tMinObj, float& closestT,
+                              StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts& cnt)
+{
+    const float4* __restrict__ nodes = sc.wide_nodes + (size_t)me.node_base * 5;
+    const float4* __restrict__ tris = sc.tris + (size_t)me.tri_base * 3;
+    const float BIG = 1e30f;
+    const int lane = slot & 63, waveBase = slot & ~63;
+    auto inverse = [&](f3 dir) { return mk3(fabsf(dir.x) > 1e-30f ? frcp(dir.x) : BIG, fabsf(dir.y) > 1e-30f ? frcp(dir.y) : BIG, fabsf(dir.z) > 1e-30f ? frcp(dir.z) : BIG); };
+    auto octant = [&](f3 iv) { return (iv.x < 0.0f ? 1u : 0u) | (iv.y < 0.0f ? 2u : 0u) | (iv.z < 0.0f ? 4u : 0u); };
+    f3 inv = inverse(d);
+    uint32_t oct = octant(inv);
+    coop.res[slot] = ((unsigned long long)__float_as_uint(closestT) << 32); // triangle field 0 = none: an equal t does not replace it
+    int owner = lane;        // whose ray this lane is working on
+    float bound = closestT;  // pruning distance of the current task
+    int sp = 0, bot = 0;     // own stack entries are [bot, sp), two rows each
+    uint32_t gBase = 0u, gBits = 0u; // current group: first inner child, (pending inner hits in traversal order) << 8 | imask
+    int node = valid ? 0 : -1;       // node to open next, or -1: take it from the current group
+    uint32_t pLeaves = 0u, pTriBase = 0u, pMeta0 = 0u, pMeta1 = 0u; // hit leaf children of the last node, not yet tested
+    for (;;) {
+        const bool wantsLeaf = pLeaves != 0u;
+        const bool wantsNode = !wantsLeaf && (node >= 0 || (gBits >> 8) != 0u || sp > bot);
+        const int nNode = __popcll(__ballot(wantsNode)), nLeaf = __popcll(__ballot(wantsLeaf));
+        if (nNode + nLeaf == 0) break;
+        if (nNode >= nLeaf) {
+            if (wantsNode) {
+                if (node < 0) {
+                    if ((gBits >> 8) == 0u) {
+                        --sp;
+                        gBase = stack[(2 * sp) * BLOCK + slot]; gBits = stack[(2 * sp + 1) * BLOCK + slot];
+                        // hits that other tasks of this ray have published (high half of the 64-bit word)
+                        bound = fminf(bound, __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(&coop.res[waveBase + owner]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+                    }
+                    const uint32_t i = (uint32_t)__ffs((int)(gBits >> 8)) - 1u;
+                    gBits &= ~(0x100u << i);
+                    const uint32_t s = i ^ oct;
+                    node = (int)(gBase + (uint32_t)__popc(gBits & 0xffu & ((1u << s) - 1u)));
+                }
+                if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
+                const float4* n = nodes + (size_t)node * 5;
+                const float4 h0 = n[0], h1 = n[1], q0 = n[2], q1 = n[3], q2 = n[4];
+                node = -1;
+                const uint32_t em = __float_as_uint(h0.w);
+                const uint32_t imask = em >> 24;
+                // this node's grid as the ray sees it: t = q * (pitch * inv) + (origin - o) * inv
+                const f3 scl = mk3(__uint_as_float((em & 255u) << 23) * inv.x, __uint_as_float(((em >> 8) & 255u) << 23) * inv.y, __uint_as_float(((em >> 16) & 255u) << 23) * inv.z);
+                const f3 off = mk3((h0.x - o.x) * inv.x, (h0.y - o.y) * inv.y, (h0.z - o.z) * inv.z);
+                const uint32_t lx0 = __float_as_uint(q0.x), lx1 = __float_as_uint(q0.y), ly0 = __float_as_uint(q0.z), ly1 = __float_as_uint(q0.w);
+                const uint32_t lz0 = __float_as_uint(q1.x), lz1 = __float_as_uint(q1.y), hx0 = __float_as_uint(q1.z), hx1 = __float_as_uint(q1.w);
+                const uint32_t hy0 = __float_as_uint(q2.x), hy1 = __float_as_uint(q2.y), hz0 = __float_as_uint(q2.z), hz1 = __float_as_uint(q2.w);
+                const bool nx = (oct & 1u) != 0u, ny = (oct & 2u) != 0u, nz = (oct & 4u) != 0u;
+                const uint32_t ax0 = nx ? hx0 : lx0, ax1 = nx ? hx1 : lx1, bx0 = nx ? lx0 : hx0, bx1 = nx ? lx1 : hx1; // a: entry planes, b: exit planes
+                const uint32_t ay0 = ny ? hy0 : ly0, ay1 = ny ? hy1 : ly1, by0 = ny ? ly0 : hy0, by1 = ny ? ly1 : hy1;
+                const uint32_t az0 = nz ? hz0 : lz0, az1 = nz ? hz1 : lz1, bz0 = nz ? lz0 : hz0, bz1 = nz ? lz1 : hz1;
+                uint32_t hit = 0u;
+#define PT_SLAB(S) hit |= wide_slab<S>(ax0, ax1, ay0, ay1, az0, az1, bx0, bx1, by0, by1, bz0, bz1, scl, off, bound)
+                PT_SLAB(0); PT_SLAB(1); PT_SLAB(2); PT_SLAB(3); PT_SLAB(4); PT_SLAB(5); PT_SLAB(6); PT_SLAB(7);
+#undef PT_SLAB
+                const uint32_t pm = permute_slots16(((hit & imask) << 8) | (hit & ~imask & 255u), oct);
+                if ((gBits >> 8) != 0u) { // the group that was being worked on waits below the new one
+                    stack[(2 * sp) * BLOCK + slot] = gBase; stack[(2 * sp + 1) * BLOCK + slot] = gBits;
+                    ++sp;
+                }
+                gBase = __float_as_uint(h1.x); gBits = (pm & 0xff00u) | imask;
+                pLeaves = pm & 255u; pTriBase = __float_as_uint(h1.y); pMeta0 = __float_as_uint(h1.z); pMeta1 = __float_as_uint(h1.w);
+            }
+            // ---- steal round: idle lanes take the oldest pending group of lanes that have one on their stack
+            const bool idle = !wantsLeaf && pLeaves == 0u && node < 0 && (gBits >> 8) == 0u && sp == bot;
+            const bool rich = sp > bot;
+            const unsigned long long idleMask = __ballot(idle), richMask = __ballot(rich);
+            if (richMask != 0ull && __popcll(idleMask) >= PT_STEAL_MIN) {
+                if (COUNT) { if (wave_leader()) ++cnt.steal_rounds; }
+                const int pairs = min(__popcll(idleMask), __popcll(richMask));
+                const int r = rank_in(idle ? idleMask : richMask);
+                const bool victim = rich && r < pairs, thief = idle && r < pairs;
+                if (victim) coop.mail[waveBase + r] = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier(); // LDS executes a wave's operations in order; this keeps the compiler from reordering them
+                int src = lane;
+                if (thief) src = (int)coop.mail[waveBase + r];
+                // every lane takes part in the cross-lane reads; a lane that is not a thief reads itself
+                o.x = __shfl(o.x, src, 64); o.y = __shfl(o.y, src, 64); o.z = __shfl(o.z, src, 64);
+                d.x = __shfl(d.x, src, 64); d.y = __shfl(d.y, src, 64); d.z = __shfl(d.z, src, 64);
+                tMinObj = __shfl(tMinObj, src, 64); bound = __shfl(bound, src, 64); owner = __shfl(owner, src, 64);
+                const int sBot = __shfl(bot, src, 64);
+                if (thief) {
+                    inv = inverse(d); oct = octant(inv);
+                    gBase = stack[(2 * sBot) * BLOCK + waveBase + src]; gBits = stack[(2 * sBot + 1) * BLOCK + waveBase + src];
+                    sp = 0; bot = 0;
+                }
+                if (victim) ++bot;
+            }
+        } else if (wantsLeaf) {
+            const uint32_t i = (uint32_t)__ffs((int)pLeaves) - 1u;
+            pLeaves &= pLeaves - 1u;
+            const uint32_t s = i ^ oct;
+            const uint32_t m = ((s & 4u ? pMeta1 : pMeta0) >> (8u * (s & 3u))) & 255u;
+            uint32_t slotIdx = pTriBase + (m & 31u), mask = m >> 6;
+            const uint32_t prims = ((m >> 5) & 1u) + 1u;
+            for (uint32_t k = 0; k < prims; ++k, mask >>= 1) {
+                if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
+                const bool quad = (mask & 1u) != 0u;
+                const uint32_t rec = slotIdx;
+                slotIdx += quad ? 2u : 1u;
+                float t, u, v, dn;
+                if (!tri_test<true>(tris + (size_t)rec * 3, o, d, tMinObj, bound, quad, t, u, v, dn)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
+                int tri = (int)rec + ((quad && u + v > 1.0f) ? 1 : 0);
+                if (me.flags & 1u) { // Mesh.cpp:106-125
+                    tri = hit_triangle(tris, (int)rec, quad, o, d, u, v, dn);
+                    if (!alpha_pass(sc, me, tri, u, v)) continue;
+                }
+                bound = t;
+                atomicMin(&coop.res[waveBase + owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((uint32_t)tri + 1u));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long best = __hip_atomic_load(&coop.res[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    closestT = __uint_as_float((uint32_t)(best >> 32));
+    return (int)(uint32_t)best - 1;
+}
+
 // Closest-hit loop of PathTracer::TraceRay (PathTracer.cpp:38-57) over the flat object list. COOP selects the
 // work-sharing traversal (every lane of the wave must then make the call together).
 template <int BLOCK, bool COUNT, bool COOP>
@@ -491,7 +649,8 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
             float closestT = best.t * dirLen;      // Mesh.cpp:72-75
             int tri = -1; float u = 0.f, v = 0.f;
             if (COOP) {
-                tri = mesh_traverse_coop<BLOCK, COUNT>(sc, geom, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt);
+                tri = (me.flags & 4u) ? mesh_traverse_wide<BLOCK, COUNT>(sc, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt)
+                                      : mesh_traverse_coop<BLOCK, COUNT>(sc, geom, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt);
                 if (!valid) tri = -1;
                 if (tri >= 0) { // the winner's own record, this lane's own ray
                     float dn;

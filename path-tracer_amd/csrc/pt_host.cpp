@@ -89,13 +89,13 @@ struct ptamd_scene {
     float background[3] = { 0.2f, 0.2f, 0.2f };
     bool committed = false;
     DevBuf<DObject> d_objects; DevBuf<DMesh> d_meshes; DevBuf<DMaterial> d_materials;
-    DevBuf<DNode> d_nodes; DevBuf<float> d_lds_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
+    DevBuf<DNode> d_nodes; DevBuf<DWideNode> d_wide; DevBuf<float> d_lds_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
     DevBuf<uint32_t> d_sky; int sky_size = 0; float sky_intensity = 1.0f;
     DScene dscene;
     void release() // what commit rebuilds; the sky map is uploaded by its own call and outlives commits
     {
-        d_objects.release(); d_meshes.release(); d_materials.release(); d_nodes.release(); d_lds_nodes.release(); d_tris.release();
+        d_objects.release(); d_meshes.release(); d_materials.release(); d_nodes.release(); d_wide.release(); d_lds_nodes.release(); d_tris.release();
         d_shade.release(); d_groups.release(); d_images.release(); d_texels.release();
     }
 };
@@ -430,6 +430,7 @@ int ptamd_scene_commit(ptamd_scene* s)
 {
     if (int rc = check_scene(s)) return rc;
     if (int rc = need_init()) return rc;
+    s->committed = false; // until every buffer of the new state has arrived
     const int maxDepth = max_stack_depth();
     std::vector<DObject> objects; std::vector<DMesh> meshes; std::vector<DMaterial> materials;
     std::vector<DNode> nodes; std::vector<DTri> tris; std::vector<DShade> shade; std::vector<DPbr> groups;
@@ -439,8 +440,44 @@ int ptamd_scene_commit(ptamd_scene* s)
     std::vector<std::pair<const HostMesh*, uint32_t>> uploaded; // geometry shared by several instances is stored once
     struct MeshSlots { uint32_t node_base, tri_base, group_base, image_base; uint32_t flags; };
     std::vector<float> ldsNodes; // LDS-format nodes of all meshes while they can still fit, kLdsNodeBytes each
-    bool ldsNodesOk = true;
     std::vector<MeshSlots> slots;
+    std::vector<DWideNode> wideNodes;
+
+    // Trees first: whether the scene's geometry is to live in LDS decides which node format (and with it which triangle
+    // order) the meshes are flattened in.
+    size_t ldsGeomBytes = 0; int stackLevels = 1;
+    {
+        std::vector<const HostMesh*> seen;
+        for (const HostObject& ho : s->objects) {
+            if (ho.kind != KIND_MESH) continue;
+            HostMesh& hm = *ho.mesh;
+            if (!hm.bvh_valid) {
+                const Model& md = hm.model;
+                hm.bvh = build_bvh(md.positions.data(), md.group.data(), md.num_faces(), maxDepth);
+                if (hm.bvh.depth > maxDepth) return fail(PTAMD_ERR_LIMIT, "BVH deeper than the traversal stack");
+                build_wide(hm.bvh);
+                hm.bvh_valid = true;
+            }
+            stackLevels = std::max(stackLevels, hm.bvh.depth);
+            if (std::find(seen.begin(), seen.end(), &hm) == seen.end()) {
+                seen.push_back(&hm);
+                ldsGeomBytes += hm.bvh.nodes.size() * kLdsNodeBytes + (size_t)hm.model.num_faces() * sizeof(DTri);
+            }
+        }
+    }
+    // small scenes are traversed from an LDS copy of their nodes (in LDS format) and hot triangles, scenes without
+    // meshes included; PTAMD_NO_LDS_GEOM (read at commit) forces the global-memory kernel for A/B tests
+    const bool ldsResident = (size_t)std::min(stackLevels, maxDepth) * 1024 + kLdsFixedBytes + ldsGeomBytes <= kLdsBlockBytes && !std::getenv("PTAMD_NO_LDS_GEOM");
+    // Large meshes of scenes that are read from global memory are walked through eight-wide quantised nodes (a stack
+    // entry of that walk takes two rows). Measured on one MI355X: a 1 M-triangle mesh, whose 64-byte binary nodes miss
+    // L2, renders 8 % faster through them (38 % fewer bytes from the memory side, 45 % more vector instructions); a
+    // 4 k-triangle mesh, which stays in L2, 20 % slower. PTAMD_NO_WIDE keeps the binary nodes and
+    // PTAMD_WIDE_MIN_FACES moves the threshold, for A/B tests.
+    const bool wideAllowed = !ldsResident && !std::getenv("PTAMD_NO_WIDE");
+    const uint32_t wideMinFaces = std::getenv("PTAMD_WIDE_MIN_FACES") ? (uint32_t)std::atoi(std::getenv("PTAMD_WIDE_MIN_FACES")) : 200000u;
+    auto uses_wide = [&](const HostMesh& hm) {
+        return wideAllowed && !hm.bvh.wide.empty() && 2 * hm.bvh.wide_depth <= maxDepth && hm.model.num_faces() >= wideMinFaces;
+    };
 
     for (const HostObject& ho : s->objects) {
         DObject d; std::memset(&d, 0, sizeof d);
@@ -460,20 +497,22 @@ int ptamd_scene_commit(ptamd_scene* s)
         } else {
             HostMesh& hm = *ho.mesh;
             const Model& md = hm.model;
-            if (!hm.bvh_valid) {
-                hm.bvh = build_bvh(md.positions.data(), md.group.data(), md.num_faces(), maxDepth);
-                hm.bvh_valid = true;
-                if (hm.bvh.depth > maxDepth) return fail(PTAMD_ERR_LIMIT, "BVH deeper than the traversal stack");
-            }
+            const bool wide = uses_wide(hm);
+            const std::vector<uint32_t>& order = wide ? hm.bvh.wide_order : hm.bvh.order;
             size_t slot = 0;
             for (; slot < uploaded.size(); ++slot) if (uploaded[slot].first == &hm) break;
             if (slot == uploaded.size()) {
                 MeshSlots ms;
-                ms.node_base = (uint32_t)nodes.size(); ms.tri_base = (uint32_t)tris.size();
-                ms.group_base = (uint32_t)groups.size(); ms.image_base = (uint32_t)images.size(); ms.flags = 0;
-                nodes.insert(nodes.end(), hm.bvh.nodes.begin(), hm.bvh.nodes.end());
-                if (ldsNodesOk && (ldsNodes.size() * 4 + hm.bvh.nodes.size() * kLdsNodeBytes <= kLdsBlockBytes)) append_lds_nodes(hm.bvh.nodes, ldsNodes);
-                else ldsNodesOk = false;
+                ms.tri_base = (uint32_t)tris.size();
+                ms.group_base = (uint32_t)groups.size(); ms.image_base = (uint32_t)images.size(); ms.flags = wide ? 4u : 0u;
+                if (wide) {
+                    ms.node_base = (uint32_t)wideNodes.size();
+                    wideNodes.insert(wideNodes.end(), hm.bvh.wide.begin(), hm.bvh.wide.end());
+                } else {
+                    ms.node_base = (uint32_t)nodes.size();
+                    nodes.insert(nodes.end(), hm.bvh.nodes.begin(), hm.bvh.nodes.end());
+                    if (ldsResident) append_lds_nodes(hm.bvh.nodes, ldsNodes);
+                }
                 std::vector<int32_t> faceMaterial; // per group: constant material slot, or -1 when the group samples images
                 for (const ptamd_pbr& g : md.groups) {
                     DPbr dg; std::memset(&dg, 0, sizeof dg);
@@ -495,7 +534,7 @@ int ptamd_scene_commit(ptamd_scene* s)
                     faceMaterial.push_back((textured || g.normal_tex >= 0) ? -1 : dg.material);
                 }
                 for (uint32_t i = 0; i < md.num_faces(); ++i) {
-                    uint32_t f = hm.bvh.order[i];
+                    uint32_t f = order[i];
                     // vertices in the order of the hot record: a quad's first triangle starts at the corner opposite the
                     // shared edge (a cyclic rotation: same triangle, same orientation)
                     const int rot = hm.bvh.rotation[f];
@@ -547,7 +586,7 @@ int ptamd_scene_commit(ptamd_scene* s)
             Mat4 Minv = inverse(M);                                                        // Mesh.cpp:54
             rows3x4(M, dm.m); rows3x4(Minv, dm.minv);
             dm.node_base = ms.node_base; dm.tri_base = ms.tri_base; dm.group_base = ms.group_base; dm.image_base = ms.image_base;
-            dm.num_tris = md.num_faces(); dm.root = hm.bvh.root; dm.flags = ms.flags;
+            dm.num_tris = md.num_faces(); dm.root = wide ? 0 : hm.bvh.root; dm.flags = ms.flags;
             d.mesh = (int32_t)meshes.size();
             meshes.push_back(dm);
         }
@@ -556,17 +595,13 @@ int ptamd_scene_commit(ptamd_scene* s)
 
     // a hit names its face by its index in the scene-wide arrays with two flag bits above it (pt_device.h: kFrontBit)
     if (tris.size() >= (size_t(1) << 30)) return fail(PTAMD_ERR_LIMIT, "scene has too many triangles (limit 2^30 - 1 over all distinct meshes)");
+    std::memset(&s->dscene, 0, sizeof(DScene)); // nothing may point at the buffers released next
     s->release();
     if (int rc = s->d_objects.upload(objects)) return rc;
     if (int rc = s->d_meshes.upload(meshes)) return rc;
     if (int rc = s->d_materials.upload(materials)) return rc;
     if (int rc = s->d_nodes.upload(nodes)) return rc;
-    // small scenes are traversed from an LDS copy of their nodes (in LDS format) and hot triangles
-    // scenes without meshes included; PTAMD_NO_LDS_GEOM (read at commit) forces the global-memory kernel for A/B tests
-    int stackLevels = 1;
-    for (const HostObject& ho : s->objects) if (ho.kind == KIND_MESH) stackLevels = std::max(stackLevels, ho.mesh->bvh.depth);
-    const size_t ldsBlock = (size_t)std::min(stackLevels, maxDepth) * 1024 + kLdsFixedBytes + ldsNodes.size() * 4 + tris.size() * sizeof(DTri);
-    const bool ldsResident = ldsNodesOk && ldsBlock <= kLdsBlockBytes && !std::getenv("PTAMD_NO_LDS_GEOM");
+    if (int rc = s->d_wide.upload(wideNodes)) return rc;
     if (ldsResident && !ldsNodes.empty()) { if (int rc = s->d_lds_nodes.upload(ldsNodes)) return rc; }
     if (int rc = s->d_tris.upload(tris)) return rc;
     if (int rc = s->d_shade.upload(shade)) return rc;
@@ -574,9 +609,10 @@ int ptamd_scene_commit(ptamd_scene* s)
     if (int rc = s->d_images.upload(images)) return rc;
     if (int rc = s->d_texels.upload(texels)) return rc;
     DScene& ds = s->dscene;
-    ds.objects = s->d_objects.ptr; ds.num_objects = (int32_t)objects.size(); ds.max_stack = maxDepth;
+    ds.objects = s->d_objects.ptr; ds.num_objects = (int32_t)objects.size();
     ds.meshes = s->d_meshes.ptr; ds.materials = s->d_materials.ptr;
     ds.nodes = reinterpret_cast<const float4*>(s->d_nodes.ptr);
+    ds.wide_nodes = reinterpret_cast<const float4*>(s->d_wide.ptr);
     ds.tris = reinterpret_cast<const float4*>(s->d_tris.ptr);
     ds.lds_resident = ldsResident ? 1u : 0u;
     ds.lds_nodes = ldsResident ? reinterpret_cast<const float4*>(s->d_lds_nodes.ptr) : nullptr; ds.lds_node_f4 = ldsResident ? (uint32_t)(ldsNodes.size() / 4) : 0u;
@@ -585,8 +621,9 @@ int ptamd_scene_commit(ptamd_scene* s)
     std::memcpy(ds.background, s->background, 12);
     ds.sky = s->sky_size ? s->d_sky.ptr : nullptr; ds.sky_size = s->sky_size; ds.sky_intensity = s->sky_intensity;
     ds.num_nodes = (uint32_t)nodes.size(); ds.num_tris = (uint32_t)tris.size();
-    ds.max_stack = 1;
-    for (const HostObject& ho : s->objects) if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, ho.mesh->bvh.depth);
+    ds.max_stack = 1; // rows of the per-lane traversal stack the deepest walk of this scene needs
+    for (const HostObject& ho : s->objects)
+        if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, uses_wide(*ho.mesh) ? 2 * ho.mesh->bvh.wide_depth : ho.mesh->bvh.depth);
     s->committed = true;
     return PTAMD_OK;
 }

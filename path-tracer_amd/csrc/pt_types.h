@@ -43,7 +43,8 @@ struct DMesh {
     uint32_t image_base;  // index of its first image
     uint32_t num_tris;
     int32_t root;         // child reference of the root (see DNode)
-    uint32_t flags;       // bit 0: some group uses alpha MASK; bit 1: some group samples a texture
+    uint32_t flags;       // bit 0: some group uses alpha MASK; bit 1: some group samples a texture; bit 2: the mesh is
+                          // traversed through DWideNode (node_base then counts 80-byte nodes, the root is node 0)
     uint32_t pad;
 };
 
@@ -56,6 +57,23 @@ struct DNode {
     float rmin2; float rmax[3];     // f4 2: r.min.z, r.max.xyz
     int32_t left, right; int32_t pad[2]; // f4 3
 };
+
+// Eight-wide node with quantised child boxes for meshes that are read from global memory, where a ray's cost is the
+// bytes it pulls through L2 (a DNode spends 32 bytes per child box, this one 10). Child boxes are stored on a grid of
+// 256 steps per axis that starts at `origin` and has a power-of-two pitch 2^(e - 127), rounded outwards. Children that
+// are inner nodes are stored contiguously from child_base in slot order, so the k-th inner slot's node is child_base +
+// (number of inner slots below k); leaf children name up to 2 primitives (4 triangle slots) inside the node's own range
+// of at most 32 triangle slots from tri_base. Slots are assigned so that visiting them in the order of (slot ^ octant
+// of the ray direction) goes roughly front to back. An empty slot has an inverted box (lo 255, hi 0) and is never hit.
+struct DWideNode {
+    float origin[3]; uint8_t ex, ey, ez, imask;       // f4 0; imask: bit s set when slot s is an inner node
+    uint32_t child_base, tri_base; uint8_t meta[8];   // f4 1; meta of a leaf slot: bits 0-4 first triangle slot (relative to
+                                                      //       tri_base), bit 5 primitives - 1, bits 6-7 quad mask
+    uint8_t qlo_x[8], qlo_y[8];                       // f4 2
+    uint8_t qlo_z[8], qhi_x[8];                       // f4 3
+    uint8_t qhi_y[8], qhi_z[8];                       // f4 4
+};
+static_assert(sizeof(DWideNode) == 80, "DWideNode is 5 float4");
 
 // Node of the LDS-resident traversal (scenes whose nodes and hot triangles fit kLdsBlockBytes), built by the host
 // next to the DNode array, one per DNode in the same order, 28 dwords. Per axis eight floats
@@ -113,6 +131,7 @@ struct DScene {
     const DMesh* meshes;
     const DMaterial* materials;
     const float4* nodes;   // DNode as 4 float4
+    const float4* wide_nodes; // DWideNode as 5 float4 (meshes with flag bit 2)
     const float4* tris;    // DTri as 3 float4
     const float4* shade;   // DShade as 7 float4
     const DPbr* groups;

@@ -309,3 +309,44 @@ def test_tiny_meshes(gpu, faces, monkeypatch):
         gpu.Render(cam, pt, film, 2, 4, seed=2)
         close = np.abs(film.Accum() - oa).max(axis=-1) <= 2e-3 + 2e-3 * np.abs(oa).max(axis=-1)
         assert close.mean() >= 0.95, close.mean()
+
+
+def test_wide_nodes_agree_with_binary_nodes(gpu, monkeypatch):
+    """Large meshes are walked through eight-wide nodes with 8-bit child boxes, smaller ones through binary nodes. With
+    the size threshold taken away (PTAMD_WIDE_MIN_FACES) the wide walk must find the same closest hits and give the same
+    per-sample radiance as the binary walk on small scenes too: an alpha-masked, textured mesh; two materials with
+    vertex normals; a 270-triangle sphere; an instanced mesh under rotation and non-uniform scale."""
+    monkeypatch.setenv("PTAMD_NO_LDS_GEOM", "1")
+    sphere = soup(gltf_io.bumpy_sphere_primitive(10, 14, radius=1.0, bump=0.05, freq=5))
+    inst = presets.cornell_room_boxes()
+    inst.append({"type": "mesh", "data": sphere, "pos": (1.6, 1.2, 2.6), "rot": (15.0, 40.0, -10.0), "scale": (0.8, 0.5, 0.6)})
+    inst.append({"type": "mesh", "data": sphere, "pos": (3.7, 2.6, 3.2), "rot": (0.0, 25.0, 65.0), "scale": (0.7, 1.2, 0.6)})
+    scenes = [presets.mixed("tests/golden/textured.glb", 96, 96, mesh_pos=(2.7, 1.6, 2.6), mesh_rot=(0.0, 25.0, 0.0), mesh_scale=(1.4, 1.4, 1.4)),
+              presets.mixed("tests/golden/blob.glb", 96, 96, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0)),
+              {"film": (96, 72), "camera": presets.default_camera(), "objects": inst}]
+    rng = np.random.default_rng(12)
+    for scene in scenes:
+        w, h = scene["film"]
+        out = []
+        o = (rng.random((4000, 3)) * 4.5 + 0.5).astype(np.float32)
+        d = rng.normal(size=(4000, 3)).astype(np.float32)
+        extra = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], 1).astype(np.float32)
+        for faces in ("1000000000", "1"):
+            monkeypatch.setenv("PTAMD_WIDE_MIN_FACES", faces)
+            pt, cam = gpu.build_scene(scene)
+            rays = cam.GetRays().reshape(-1, 6)
+            hits, cnt = pt.TraversalCounts(np.concatenate([rays, extra]))
+            film = gpu.Film(w, h)
+            gpu.Render(cam, pt, film, 3, 6, seed=31, count=True)
+            out.append((hits, cnt, film.Accum(), gpu.RenderStats()))
+        (hb, cb, fb, sb), (hw, cw, fw, sw) = out
+        assert cw[:, 0].sum() < 0.7 * cb[:, 0].sum()  # far fewer node visits: the wide walk really ran
+        assert (hb[:, 0] == hw[:, 0]).mean() >= 0.9995
+        hit = (hb[:, 0] == 1) & (hw[:, 0] == 1)
+        same = hit & (np.abs(hb[:, 1] - hw[:, 1]) <= 1e-6 * np.abs(hb[:, 1]))
+        assert same.sum() >= 0.999 * hit.sum()  # rays through shared edges may settle on the neighbour
+        assert np.abs(hb[same, 2:8] - hw[same, 2:8]).max() <= 1e-5
+        assert np.array_equal(hb[same, 8:], hw[same, 8:])
+        close = np.abs(fb - fw).max(axis=-1) <= 1e-4 + 1e-4 * np.abs(fb).max(axis=-1)
+        assert close.mean() >= 0.99, close.mean()
+        assert sb["samples"] == sw["samples"] and sw["steal_rounds"] > 0

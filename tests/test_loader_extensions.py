@@ -120,3 +120,62 @@ def test_material_pointing_at_a_missing_image_is_refused(tmp_path):
     open(path, "w").write(json.dumps(doc))
     with pytest.raises(ptamd.PtamdError, match="image that the file does not hold"):
         ptamd.load_model(path)
+
+
+def _doc_and_blob(tmp_path):
+    import base64
+    import json
+    import struct
+    prim = gltf_io.box_primitive((0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    mat = gltf_io.gltf_material("m", [0.8, 0.2, 0.2, 0.5, 0.0, 1, 1, 1, 0.0, 1.5, 0.0])
+    gltf_io.write_glb(str(tmp_path / "ok.glb"), [prim], [mat])
+    raw = open(tmp_path / "ok.glb", "rb").read()
+    n = struct.unpack_from("<I", raw, 12)[0]
+    doc = json.loads(raw[20:20 + n])
+    blob = raw[20 + n + 8:]
+    doc["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+    return doc
+
+
+@pytest.mark.parametrize("edit", [
+    lambda d: d["accessors"][0].__setitem__("count", 2 ** 62),                       # count * stride wraps around 2^64
+    lambda d: (d["bufferViews"][0].__setitem__("byteStride", 2 ** 63), d["accessors"][0].__setitem__("count", 3)),
+    lambda d: d["bufferViews"][0].__setitem__("byteOffset", -8),
+    lambda d: d["accessors"][0].__setitem__("byteOffset", 1e300),
+    lambda d: d["accessors"][0].__setitem__("count", 2.5),
+    lambda d: d["accessors"][0].__setitem__("bufferView", -1),
+    lambda d: d["accessors"][0].__setitem__("count", 1 << 40),                        # valid number, far past the buffer
+    lambda d: d["meshes"][0]["primitives"][0].__setitem__("indices", 1e20),
+    lambda d: d["meshes"][0]["primitives"][0]["attributes"].__setitem__("POSITION", "zero"),
+])
+def test_hostile_numbers_in_a_model_file_are_refused(tmp_path, edit):
+    """Counts, offsets, strides and indices of a file are validated before any pointer arithmetic: negative, huge,
+    fractional or non-numeric values raise a clean error (the reference gets the same protection from tinygltf)."""
+    import json
+    doc = _doc_and_blob(tmp_path)
+    edit(doc)
+    path = str(tmp_path / "bad.gltf")
+    open(path, "w").write(json.dumps(doc))
+    with pytest.raises(ptamd.PtamdError):
+        ptamd.load_model(path)
+
+
+def test_deeply_nested_json_and_short_png_header_are_refused(tmp_path):
+    import base64
+    import json
+    import struct
+    import zlib
+    path = str(tmp_path / "deep.gltf")
+    open(path, "w").write("[" * 200000)
+    with pytest.raises(ptamd.PtamdError, match="nesting"):
+        ptamd.load_model(path)
+    # a PNG whose IHDR chunk is shorter than its 13 bytes
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">II", 4, 4)) + chunk(b"IEND", b"")
+    doc = _doc_and_blob(tmp_path)
+    doc["images"] = [{"uri": "data:image/png;base64," + base64.b64encode(png).decode()}]
+    path = str(tmp_path / "png.gltf")
+    open(path, "w").write(json.dumps(doc))
+    with pytest.raises(ptamd.PtamdError, match="PNG"):
+        ptamd.load_model(path)
