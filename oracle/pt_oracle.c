@@ -190,10 +190,13 @@ uint32_t po_path_key(uint32_t seed, uint32_t pixel, uint32_t sample)
     k = po_pcg_hash(k + sample * 0x9E3779B9u);
     return k;
 }
-/* Replaces Rand01 (PathTracer.cpp:13-16): uniform in [0,1) with 24 random bits. */
+/* Replaces Rand01 (PathTracer.cpp:13-16): uniform in [0,1) with 24 random bits. The draw counter enters through a
+ * multiply and an exclusive-or, not an addition: key + counter would make the streams of two paths whose keys differ
+ * by less than 256 share draws in shifted positions, and at 1080p x 1024 spp the 2^31 keys fill half of the 32-bit
+ * space. */
 float po_rand01(uint32_t key, uint32_t bounce, uint32_t draw)
 {
-    uint32_t r = po_pcg_hash(key + bounce * 8u + draw);
+    uint32_t r = po_pcg_hash(key ^ ((bounce * 8u + draw + 1u) * 0x9E3779B9u));
     return (float)(r >> 8) * 5.9604644775390625e-8f;
 }
 typedef struct { uint32_t key, bounce, draw; uint32_t flags; v3 thr; } rng_t; /* flags/thr: extension state (Russian roulette) */

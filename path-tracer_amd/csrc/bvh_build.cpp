@@ -178,8 +178,11 @@ struct Builder {
 
 namespace {
 // Pairs triangles that share an edge and form a parallelogram: for A = (a, b, c) the partner must consist of b, c
-// and d = b + c - a (within rounding of the coordinates), in the same material group. Greedy, first match wins.
-void pair_quads(const float* P, const int32_t* group, uint32_t n, float tol, std::vector<uint32_t>& primA, std::vector<uint32_t>& primB,
+// and d = b + c - a, in the same material group. Greedy, first match wins. The second triangle is then hit-tested
+// through the first one's plane, so d may be off by no more than rounding: 2e-6 of the pair's own longest edge plus
+// two units in the last place of its largest coordinate (a tolerance taken from the whole mesh's extent would, for a
+// small feature far from the origin, approach the feature's size).
+void pair_quads(const float* P, const int32_t* group, uint32_t n, std::vector<uint32_t>& primA, std::vector<uint32_t>& primB,
                 std::vector<int>& rotation)
 {
     struct Key { uint32_t v[6]; bool operator==(const Key& o) const { return !std::memcmp(v, o.v, sizeof v); } };
@@ -215,6 +218,12 @@ void pair_quads(const float* P, const int32_t* group, uint32_t n, float tol, std
                     if (std::memcmp(v, b, 12) && std::memcmp(v, c, 12)) d = v;
                 }
                 if (!d) continue;
+                float edge = 0.f, coord = 0.f;
+                for (int k = 0; k < 3; ++k) {
+                    edge = std::max(edge, std::max(std::fabs(b[k] - a[k]), std::fabs(c[k] - a[k])));
+                    coord = std::max(std::max(coord, std::fabs(a[k])), std::max(std::max(std::fabs(b[k]), std::fabs(c[k])), std::fabs(d[k])));
+                }
+                const float tol = 2e-6f * edge + 2.4e-7f * coord;
                 bool ok = true;
                 for (int k = 0; k < 3; ++k) ok = ok && std::fabs(d[k] - (b[k] + c[k] - a[k])) <= tol;
                 if (!ok) continue;
@@ -245,7 +254,7 @@ BvhResult build_bvh(const float* P, const int32_t* group, uint32_t n, int max_de
     float scale = 0.f;
     for (int k = 0; k < 3; ++k) scale = std::max(scale, std::max(std::fabs(all.lo[k]), std::fabs(all.hi[k])));
     const bool quads = !std::getenv("PTAMD_NO_QUADS");
-    if (quads) pair_quads(P, group, n, 2e-6f * std::max(scale, 1e-20f), b.primA, b.primB, res.rotation);
+    if (quads) pair_quads(P, group, n, b.primA, b.primB, res.rotation);
     else { for (uint32_t i = 0; i < n; ++i) { b.primA.push_back(i); b.primB.push_back(Builder::kNone); } res.rotation.assign(n, 0); }
     const uint32_t np = (uint32_t)b.primA.size();
     b.fb.resize(np); b.fc.resize(3 * (size_t)np); b.idx.resize(np);

@@ -26,7 +26,8 @@ PT_DEV float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
 
 // ---------------------------------------------------------------- random source
 // Counter-based replacement for the reference's thread_local mt19937 (PathTracer.cpp:8-16): a PCG
-// output hash keyed by (seed, pixel, sample, bounce, draw). Bit-identical to oracle/pt_oracle.c.
+// output hash keyed by (seed, pixel, sample, bounce, draw). Bit-identical to oracle/pt_oracle.c. The draw counter is
+// mixed in by a multiply and an exclusive-or: added to the key it would let paths with nearby keys share draws.
 PT_DEV uint32_t pcg_hash(uint32_t v)
 {
     uint32_t s = v * 747796405u + 2891336453u;
@@ -40,7 +41,7 @@ PT_DEV uint32_t path_key(uint32_t seed_hash, uint32_t pixel, uint32_t sample)
 }
 PT_DEV float rand01(uint32_t key, uint32_t bounce, uint32_t draw)
 {
-    uint32_t r = pcg_hash(key + bounce * 8u + draw);
+    uint32_t r = pcg_hash(key ^ ((bounce * 8u + draw + 1u) * 0x9E3779B9u));
     return (float)(r >> 8) * 5.9604644775390625e-8f;
 }
 

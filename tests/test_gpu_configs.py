@@ -350,3 +350,26 @@ def test_wide_nodes_agree_with_binary_nodes(gpu, monkeypatch):
         close = np.abs(fb - fw).max(axis=-1) <= 1e-4 + 1e-4 * np.abs(fb).max(axis=-1)
         assert close.mean() >= 0.99, close.mean()
         assert sb["samples"] == sw["samples"] and sw["steal_rounds"] > 0
+
+
+def test_quads_far_from_the_origin(gpu, monkeypatch):
+    """The Cornell mesh moved 10^4 units from the origin, where a float coordinate resolves 10^-3: faces whose fourth
+    corner no longer sits within rounding of b + c - a must not be paired, and whatever is paired must give the closest
+    hits of the separate triangles."""
+    src = gltf_io.load_gltf("tests/golden/cornell_mesh.glb")
+    shift = np.array([1.0e4, -7.0e3, 4.0e3], np.float32)
+    data = dict(src, positions=(src["positions"].reshape(-1, 3) + shift).reshape(-1, 9).astype(np.float32))
+    cam = dict(presets.default_camera())
+    cam["pos"] = tuple(float(x) for x in (np.array(cam["pos"], np.float32) + shift))
+    scene = {"film": (96, 54), "camera": cam, "objects": [{"type": "mesh", "data": data, "pos": (0, 0, 0), "rot": (0, 0, 0), "scale": (1, 1, 1)}]}
+    pt, camera = gpu.build_scene(scene)
+    rays = camera.GetRays().reshape(-1, 6)
+    a = pt.ClosestHits(rays)
+    monkeypatch.setenv("PTAMD_NO_QUADS", "1")
+    pt2, _ = gpu.build_scene(scene)
+    b = pt2.ClosestHits(rays)
+    assert a[:, 0].mean() > 0.5 and (a[:, 0] == b[:, 0]).mean() >= 0.999
+    hit = (a[:, 0] == 1) & (b[:, 0] == 1)
+    # at these coordinates t itself carries ~1e-3 of rounding from the hit point's position
+    assert (np.abs(a[hit, 1] - b[hit, 1]) <= 4e-3).mean() >= 0.999
+    assert np.array_equal(a[hit, 9:12], b[hit, 9:12]) or (np.all(a[hit, 9:12] == b[hit, 9:12], axis=1)).mean() >= 0.999
