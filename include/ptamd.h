@@ -155,9 +155,24 @@ int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3]);
  * faces == NULL or face_size <= 0 removes it. Takes effect at once; no commit needed. */
 int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const faces[6], float intensity);
 /* Flattens the object list into SoA device buffers, builds and linearises the per-mesh BVHs
- * (replaces Mesh::BuildBVH, Mesh.cpp:289-397) and uploads. Re-callable after edits; only meshes
- * whose triangles changed are rebuilt. */
+ * (replaces Mesh::BuildBVH, Mesh.cpp:289-397) and uploads. Re-callable after edits; trees are built once per
+ * mesh, and edits that leave the geometry alone rewrite single table rows (see ptamd_scene_get_info). */
 int ptamd_scene_commit(ptamd_scene* s);
+/* No reference counterpart (diagnostics of the upload path). A commit after edits of transforms, radii, sizes, materials
+ * or material-group factors rewrites only the rows concerned (objects / instances / materials / groups): geometry
+ * buffers keep their addresses and geometry_uploads does not move. Adding or removing objects, or making a group start
+ * or stop sampling images or masking, uploads everything again. */
+typedef struct ptamd_scene_info {
+    uint32_t objects, meshes, triangles, nodes, wide_nodes, lds_resident;
+    uint64_t geometry_uploads;   /* full flatten + upload passes so far */
+    uint64_t row_updates;        /* table rows rewritten by incremental commits so far */
+    double last_commit_seconds;  /* host time of the last ptamd_scene_commit */
+    double last_bvh_seconds;     /* of which BVH construction (0 when the trees were still valid) */
+    const void* d_nodes;         /* device addresses of the geometry buffers (identity checks only) */
+    const void* d_tris;
+    const void* d_shade;
+} ptamd_scene_info;
+int ptamd_scene_get_info(const ptamd_scene* s, ptamd_scene_info* out);
 
 /* ---- model ingest: ModelLoader::LoadGLTF (ModelLoader.h:171-420) ---------------------------- */
 int ptamd_model_load(const char* path, ptamd_model** out);

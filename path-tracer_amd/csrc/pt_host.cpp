@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -88,6 +89,15 @@ struct ptamd_scene {
     std::vector<HostObject> objects;
     float background[3] = { 0.2f, 0.2f, 0.2f };
     bool committed = false;
+    // What the next commit has to do. structure_dirty: the object list, a mesh's triangles or a group's use of images
+    // changed, so everything is flattened and uploaded again. Otherwise only the rows named by `edits` (per object:
+    // 1 transform / shape, 2 material, 4 a mesh's material groups) are rewritten in the small tables; nodes, triangles,
+    // shading records and texels stay where they are.
+    bool structure_dirty = true;
+    std::vector<uint8_t> edits;
+    std::vector<DObject> h_objects; std::vector<DMesh> h_meshes; std::vector<DPbr> h_groups; // host mirrors of the last full commit
+    uint64_t geometry_uploads = 0, row_updates = 0;
+    double last_commit_seconds = 0.0, last_bvh_seconds = 0.0;
     DevBuf<DObject> d_objects; DevBuf<DMesh> d_meshes; DevBuf<DMaterial> d_materials;
     DevBuf<DNode> d_nodes; DevBuf<DWideNode> d_wide; DevBuf<float> d_lds_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
@@ -195,6 +205,53 @@ int copy_mesh_desc(const ptamd_mesh_desc* d, Model& m)
     return PTAMD_OK;
 }
 
+// Geometry fields of a sphere's or box's row (kind, material and mesh stay as they are).
+void fill_object_row(const HostObject& ho, DObject& d)
+{
+    std::memcpy(d.c, ho.pos, 12);
+    if (ho.kind == KIND_SPHERE) { d.radius = ho.radius; return; }
+    for (int k = 0; k < 3; ++k) d.half[k] = ho.size[k] * 0.5f;                     // Box.cpp:30
+    d.eps = 1e-4f * std::max(std::max(d.half[0], d.half[1]), d.half[2]);          // Box.cpp:63
+    Mat4 R = rotate_euler_xyz(Mat4::identity(), ho.rot);                          // Box.cpp:16-19
+    for (int k = 0; k < 3; ++k) { d.ax0[k] = R.m[0][k]; d.ax1[k] = R.m[1][k]; d.ax2[k] = R.m[2][k]; }
+    d.aligned = d.ax0[0] == 1.f && d.ax0[1] == 0.f && d.ax0[2] == 0.f && d.ax1[0] == 0.f && d.ax1[1] == 1.f && d.ax1[2] == 0.f
+                && d.ax2[0] == 0.f && d.ax2[1] == 0.f && d.ax2[2] == 1.f;
+}
+// Instance matrices of a mesh (Mesh.cpp:47-54).
+void fill_mesh_matrices(const HostObject& ho, DMesh& dm)
+{
+    Mat4 M = translate(Mat4::identity(), ho.pos);
+    M = rotate_euler_xyz(M, ho.rot);
+    M = scale(M, ho.size);
+    Mat4 Minv = inverse(M);
+    rows3x4(M, dm.m); rows3x4(Minv, dm.minv);
+}
+bool group_samples_images(const ptamd_pbr& g)
+{
+    return g.base_color_tex >= 0 || g.metallic_roughness_tex >= 0 || g.emissive_tex >= 0 || g.transmission_tex >= 0 || g.normal_tex >= 0;
+}
+DPbr make_dpbr(const ptamd_pbr& g, uint32_t image_base, int32_t material_row)
+{
+    DPbr dg; std::memset(&dg, 0, sizeof dg);
+    auto img = [&](int32_t t) { return t >= 0 ? (int32_t)(image_base + (uint32_t)t) : -1; };
+    dg.base_color_tex = img(g.base_color_tex); dg.normal_tex = img(g.normal_tex);
+    dg.metallic_roughness_tex = img(g.metallic_roughness_tex); dg.emissive_tex = img(g.emissive_tex);
+    dg.transmission_tex = img(g.transmission_tex);
+    dg.alpha_mode = g.alpha_mode; dg.alpha_cutoff = g.alpha_cutoff; dg.normal_scale = g.normal_scale;
+    std::memcpy(dg.base_color_factor, g.base_color_factor, 16);
+    std::memcpy(dg.emissive_factor, g.emissive_factor, 12);
+    dg.metallic_factor = g.metallic_factor; dg.roughness_factor = g.roughness_factor;
+    dg.transmission_factor = g.transmission_factor; dg.ior = g.ior;
+    dg.material = material_row;
+    return dg;
+}
+void mark_edit(ptamd_scene* s, int object, uint8_t what)
+{
+    if (s->edits.size() < s->objects.size()) s->edits.resize(s->objects.size(), 0);
+    s->edits[(size_t)object] |= what;
+    s->committed = false;
+}
+
 DCamera make_camera(const ptamd_camera& c, int w, int h)
 {
     // Camera::CalculateMatrices (Camera.cpp:22-35)
@@ -284,7 +341,7 @@ int ptamd_scene_destroy(ptamd_scene* s)
 int ptamd_scene_clear(ptamd_scene* s)
 {
     if (int rc = check_scene(s)) return rc;
-    s->objects.clear(); s->committed = false;
+    s->objects.clear(); s->committed = false; s->structure_dirty = true;
     return PTAMD_OK;
 }
 int ptamd_scene_object_count(const ptamd_scene* s) { return s ? (int)s->objects.size() : fail(PTAMD_ERR_ARG, "null scene handle"); }
@@ -295,7 +352,7 @@ int ptamd_scene_add_sphere(ptamd_scene* s, const float pos[3], float radius, con
     if (!pos) return fail(PTAMD_ERR_ARG, "null position");
     HostObject o; o.kind = KIND_SPHERE; std::memcpy(o.pos, pos, 12); o.radius = radius;
     if (mat) o.mat = *mat; else ptamd_material_default(&o.mat);
-    s->objects.push_back(o); s->committed = false;
+    s->objects.push_back(o); s->committed = false; s->structure_dirty = true;
     return (int)s->objects.size() - 1;
 }
 int ptamd_scene_add_box(ptamd_scene* s, const float pos[3], const float rot[3], const float size[3], const ptamd_material* mat)
@@ -305,7 +362,7 @@ int ptamd_scene_add_box(ptamd_scene* s, const float pos[3], const float rot[3], 
     HostObject o; o.kind = KIND_BOX; std::memcpy(o.pos, pos, 12); std::memcpy(o.size, size, 12);
     if (rot) std::memcpy(o.rot, rot, 12);
     if (mat) o.mat = *mat; else ptamd_material_default(&o.mat);
-    s->objects.push_back(o); s->committed = false;
+    s->objects.push_back(o); s->committed = false; s->structure_dirty = true;
     return (int)s->objects.size() - 1;
 }
 static int add_mesh_object(ptamd_scene* s, std::shared_ptr<HostMesh> hm, const float pos[3], const float rot[3], const float scl[3])
@@ -315,7 +372,7 @@ static int add_mesh_object(ptamd_scene* s, std::shared_ptr<HostMesh> hm, const f
     if (pos) std::memcpy(o.pos, pos, 12);
     if (rot) std::memcpy(o.rot, rot, 12);
     if (scl) std::memcpy(o.size, scl, 12);
-    s->objects.push_back(o); s->committed = false;
+    s->objects.push_back(o); s->committed = false; s->structure_dirty = true;
     return (int)s->objects.size() - 1;
 }
 int ptamd_scene_add_mesh(ptamd_scene* s, const ptamd_mesh_desc* mesh, const float pos[3], const float rot[3], const float scl[3])
@@ -346,14 +403,14 @@ int ptamd_scene_set_transform(ptamd_scene* s, int object, const float pos[3], co
     if (pos) std::memcpy(o.pos, pos, 12);
     if (rot) std::memcpy(o.rot, rot, 12);
     if (size) std::memcpy(o.size, size, 12);
-    s->committed = false;
+    mark_edit(s, object, 1);
     return PTAMD_OK;
 }
 int ptamd_scene_set_radius(ptamd_scene* s, int object, float radius)
 {
     if (int rc = check_object(s, object)) return rc;
     if (s->objects[(size_t)object].kind != KIND_SPHERE) return fail(PTAMD_ERR_ARG, "object is not a sphere");
-    s->objects[(size_t)object].radius = radius; s->committed = false;
+    s->objects[(size_t)object].radius = radius; mark_edit(s, object, 1);
     return PTAMD_OK;
 }
 int ptamd_scene_set_material(ptamd_scene* s, int object, const ptamd_material* mat)
@@ -361,7 +418,7 @@ int ptamd_scene_set_material(ptamd_scene* s, int object, const ptamd_material* m
     if (int rc = check_object(s, object)) return rc;
     if (!mat) return fail(PTAMD_ERR_ARG, "null material");
     if (s->objects[(size_t)object].kind == KIND_MESH) return fail(PTAMD_ERR_ARG, "mesh materials are edited per group (ptamd_scene_set_mesh_group)");
-    s->objects[(size_t)object].mat = *mat; s->committed = false;
+    s->objects[(size_t)object].mat = *mat; mark_edit(s, object, 2);
     return PTAMD_OK;
 }
 int ptamd_scene_set_mesh_group(ptamd_scene* s, int object, uint32_t group, const ptamd_pbr* pbr)
@@ -372,7 +429,10 @@ int ptamd_scene_set_mesh_group(ptamd_scene* s, int object, uint32_t group, const
     if (!pbr || group >= o.mesh->model.groups.size()) return fail(PTAMD_ERR_ARG, "bad material group");
     const int32_t tex[5] = { pbr->base_color_tex, pbr->normal_tex, pbr->metallic_roughness_tex, pbr->emissive_tex, pbr->transmission_tex };
     for (int32_t t : tex) if (t >= (int32_t)o.mesh->model.images.size()) return fail(PTAMD_ERR_ARG, "material group references an image that was not supplied");
-    o.mesh->model.groups[group] = *pbr; s->committed = false;
+    const ptamd_pbr& old = o.mesh->model.groups[group];
+    // a group that starts or stops sampling images, or masking, changes per-face records and mesh flags: full commit
+    if (group_samples_images(old) != group_samples_images(*pbr) || (old.alpha_mode == 1) != (pbr->alpha_mode == 1)) s->structure_dirty = true;
+    o.mesh->model.groups[group] = *pbr; mark_edit(s, object, 4);
     return PTAMD_OK;
 }
 int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3])
@@ -380,7 +440,7 @@ int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3])
     if (int rc = check_scene(s)) return rc;
     if (!rgb) return fail(PTAMD_ERR_ARG, "null colour");
     std::memcpy(s->background, rgb, 12);
-    if (s->committed) std::memcpy(s->dscene.background, rgb, 12);
+    std::memcpy(s->dscene.background, rgb, 12); // passed by value with every launch: no commit needed
     return PTAMD_OK;
 }
 
@@ -430,7 +490,53 @@ int ptamd_scene_commit(ptamd_scene* s)
 {
     if (int rc = check_scene(s)) return rc;
     if (int rc = need_init()) return rc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto seconds_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    if (!s->structure_dirty && s->h_objects.size() == s->objects.size()) {
+        // Only rows of the small tables changed since the last full commit: rewrite those, on the library stream, behind
+        // whatever launch still reads the old values.
+        s->edits.resize(s->objects.size(), 0);
+        for (size_t i = 0; i < s->objects.size(); ++i) {
+            const uint8_t what = s->edits[i];
+            if (!what) continue;
+            const HostObject& ho = s->objects[i];
+            DObject& row = s->h_objects[i];
+            if (ho.kind == KIND_MESH) {
+                DMesh& dm = s->h_meshes[(size_t)row.mesh];
+                if (what & 1) {
+                    fill_mesh_matrices(ho, dm);
+                    PT_HIP(hipMemcpyAsync(s->d_meshes.ptr + row.mesh, &dm, sizeof(DMesh), hipMemcpyHostToDevice, g_stream)); ++s->row_updates;
+                }
+                if (what & 4) {
+                    const std::vector<ptamd_pbr>& gs = ho.mesh->model.groups;
+                    for (size_t g = 0; g < gs.size(); ++g) {
+                        DPbr& dg = s->h_groups[dm.group_base + g];
+                        dg = make_dpbr(gs[g], dm.image_base, dg.material);
+                        const DMaterial m = to_dmaterial(group_material(gs[g]));
+                        PT_HIP(hipMemcpyAsync(s->d_groups.ptr + dm.group_base + g, &dg, sizeof(DPbr), hipMemcpyHostToDevice, g_stream));
+                        PT_HIP(hipMemcpyAsync(s->d_materials.ptr + dg.material, &m, sizeof(DMaterial), hipMemcpyHostToDevice, g_stream));
+                        s->row_updates += 2;
+                    }
+                }
+            } else {
+                if (what & 1) {
+                    fill_object_row(ho, row);
+                    PT_HIP(hipMemcpyAsync(s->d_objects.ptr + i, &row, sizeof(DObject), hipMemcpyHostToDevice, g_stream)); ++s->row_updates;
+                }
+                if (what & 2) {
+                    const DMaterial m = to_dmaterial(ho.mat);
+                    PT_HIP(hipMemcpyAsync(s->d_materials.ptr + row.material, &m, sizeof(DMaterial), hipMemcpyHostToDevice, g_stream)); ++s->row_updates;
+                }
+            }
+            s->edits[i] = 0;
+        }
+        PT_HIP(hipStreamSynchronize(g_stream)); // the copies read host rows that the next edit may change
+        s->committed = true;
+        s->last_commit_seconds = seconds_since(t_begin);
+        return PTAMD_OK;
+    }
     s->committed = false; // until every buffer of the new state has arrived
+    double bvhSeconds = 0.0;
     const int maxDepth = max_stack_depth();
     std::vector<DObject> objects; std::vector<DMesh> meshes; std::vector<DMaterial> materials;
     std::vector<DNode> nodes; std::vector<DTri> tris; std::vector<DShade> shade; std::vector<DPbr> groups;
@@ -453,10 +559,12 @@ int ptamd_scene_commit(ptamd_scene* s)
             HostMesh& hm = *ho.mesh;
             if (!hm.bvh_valid) {
                 const Model& md = hm.model;
+                const auto t0 = std::chrono::steady_clock::now();
                 hm.bvh = build_bvh(md.positions.data(), md.group.data(), md.num_faces(), maxDepth);
                 if (hm.bvh.depth > maxDepth) return fail(PTAMD_ERR_LIMIT, "BVH deeper than the traversal stack");
                 build_wide(hm.bvh);
                 hm.bvh_valid = true;
+                bvhSeconds += seconds_since(t0);
             }
             stackLevels = std::max(stackLevels, hm.bvh.depth);
             if (std::find(seen.begin(), seen.end(), &hm) == seen.end()) {
@@ -482,17 +590,8 @@ int ptamd_scene_commit(ptamd_scene* s)
     for (const HostObject& ho : s->objects) {
         DObject d; std::memset(&d, 0, sizeof d);
         d.kind = ho.kind; d.mesh = -1; d.material = 0;
-        if (ho.kind == KIND_SPHERE) {
-            std::memcpy(d.c, ho.pos, 12); d.radius = ho.radius;
-            d.material = (int32_t)materials.size(); materials.push_back(to_dmaterial(ho.mat));
-        } else if (ho.kind == KIND_BOX) {
-            std::memcpy(d.c, ho.pos, 12);
-            for (int k = 0; k < 3; ++k) d.half[k] = ho.size[k] * 0.5f;                     // Box.cpp:30
-            d.eps = 1e-4f * std::max(std::max(d.half[0], d.half[1]), d.half[2]);          // Box.cpp:63
-            Mat4 R = rotate_euler_xyz(Mat4::identity(), ho.rot);                          // Box.cpp:16-19
-            for (int k = 0; k < 3; ++k) { d.ax0[k] = R.m[0][k]; d.ax1[k] = R.m[1][k]; d.ax2[k] = R.m[2][k]; }
-            d.aligned = d.ax0[0] == 1.f && d.ax0[1] == 0.f && d.ax0[2] == 0.f && d.ax1[0] == 0.f && d.ax1[1] == 1.f && d.ax1[2] == 0.f
-                        && d.ax2[0] == 0.f && d.ax2[1] == 0.f && d.ax2[2] == 1.f;
+        if (ho.kind == KIND_SPHERE || ho.kind == KIND_BOX) {
+            fill_object_row(ho, d);
             d.material = (int32_t)materials.size(); materials.push_back(to_dmaterial(ho.mat));
         } else {
             HostMesh& hm = *ho.mesh;
@@ -515,23 +614,12 @@ int ptamd_scene_commit(ptamd_scene* s)
                 }
                 std::vector<int32_t> faceMaterial; // per group: constant material slot, or -1 when the group samples images
                 for (const ptamd_pbr& g : md.groups) {
-                    DPbr dg; std::memset(&dg, 0, sizeof dg);
-                    auto img = [&](int32_t t) { return t >= 0 ? (int32_t)(ms.image_base + (uint32_t)t) : -1; };
-                    dg.base_color_tex = img(g.base_color_tex); dg.normal_tex = img(g.normal_tex);
-                    dg.metallic_roughness_tex = img(g.metallic_roughness_tex); dg.emissive_tex = img(g.emissive_tex);
-                    dg.transmission_tex = img(g.transmission_tex);
-                    dg.alpha_mode = g.alpha_mode; dg.alpha_cutoff = g.alpha_cutoff; dg.normal_scale = g.normal_scale;
-                    std::memcpy(dg.base_color_factor, g.base_color_factor, 16);
-                    std::memcpy(dg.emissive_factor, g.emissive_factor, 12);
-                    dg.metallic_factor = g.metallic_factor; dg.roughness_factor = g.roughness_factor;
-                    dg.transmission_factor = g.transmission_factor; dg.ior = g.ior;
-                    dg.material = (int32_t)materials.size();
+                    const DPbr dg = make_dpbr(g, ms.image_base, (int32_t)materials.size());
                     materials.push_back(to_dmaterial(group_material(g)));
                     if (g.alpha_mode == 1) ms.flags |= 1u;
-                    const bool textured = g.base_color_tex >= 0 || g.metallic_roughness_tex >= 0 || g.emissive_tex >= 0 || g.transmission_tex >= 0;
-                    if (textured || g.normal_tex >= 0) ms.flags |= 2u;
+                    if (group_samples_images(g)) ms.flags |= 2u;
                     groups.push_back(dg);
-                    faceMaterial.push_back((textured || g.normal_tex >= 0) ? -1 : dg.material);
+                    faceMaterial.push_back(group_samples_images(g) ? -1 : dg.material);
                 }
                 for (uint32_t i = 0; i < md.num_faces(); ++i) {
                     uint32_t f = order[i];
@@ -580,11 +668,7 @@ int ptamd_scene_commit(ptamd_scene* s)
             }
             const MeshSlots& ms = slots[uploaded[slot].second];
             DMesh dm; std::memset(&dm, 0, sizeof dm);
-            Mat4 M = translate(Mat4::identity(), ho.pos);                                  // Mesh.cpp:47-52
-            M = rotate_euler_xyz(M, ho.rot);
-            M = scale(M, ho.size);
-            Mat4 Minv = inverse(M);                                                        // Mesh.cpp:54
-            rows3x4(M, dm.m); rows3x4(Minv, dm.minv);
+            fill_mesh_matrices(ho, dm);
             dm.node_base = ms.node_base; dm.tri_base = ms.tri_base; dm.group_base = ms.group_base; dm.image_base = ms.image_base;
             dm.num_tris = md.num_faces(); dm.root = wide ? 0 : hm.bvh.root; dm.flags = ms.flags;
             d.mesh = (int32_t)meshes.size();
@@ -624,7 +708,25 @@ int ptamd_scene_commit(ptamd_scene* s)
     ds.max_stack = 1; // rows of the per-lane traversal stack the deepest walk of this scene needs
     for (const HostObject& ho : s->objects)
         if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, uses_wide(*ho.mesh) ? 2 * ho.mesh->bvh.wide_depth : ho.mesh->bvh.depth);
+    s->h_objects = std::move(objects); s->h_meshes = std::move(meshes); s->h_groups = std::move(groups);
+    s->edits.assign(s->objects.size(), 0);
+    s->structure_dirty = false;
+    ++s->geometry_uploads;
     s->committed = true;
+    s->last_bvh_seconds = bvhSeconds;
+    s->last_commit_seconds = seconds_since(t_begin);
+    return PTAMD_OK;
+}
+int ptamd_scene_get_info(const ptamd_scene* s, ptamd_scene_info* out)
+{
+    if (!s || !out) return fail(PTAMD_ERR_ARG, "null argument");
+    std::memset(out, 0, sizeof *out);
+    out->objects = (uint32_t)s->objects.size(); out->meshes = (uint32_t)s->h_meshes.size();
+    out->triangles = s->dscene.num_tris; out->nodes = (uint32_t)s->d_nodes.count; out->wide_nodes = (uint32_t)s->d_wide.count;
+    out->lds_resident = s->dscene.lds_resident;
+    out->geometry_uploads = s->geometry_uploads; out->row_updates = s->row_updates;
+    out->last_commit_seconds = s->last_commit_seconds; out->last_bvh_seconds = s->last_bvh_seconds;
+    out->d_nodes = s->d_wide.count ? (const void*)s->d_wide.ptr : (const void*)s->d_nodes.ptr; out->d_tris = s->d_tris.ptr; out->d_shade = s->d_shade.ptr;
     return PTAMD_OK;
 }
 

@@ -62,6 +62,13 @@ class CStats(C.Structure):
                                           "shade_lanes", "shade_trips", "steal_rounds")]
 
 
+class CSceneInfo(C.Structure):
+    _fields_ = [("objects", C.c_uint32), ("meshes", C.c_uint32), ("triangles", C.c_uint32), ("nodes", C.c_uint32),
+                ("wide_nodes", C.c_uint32), ("lds_resident", C.c_uint32), ("geometry_uploads", C.c_uint64),
+                ("row_updates", C.c_uint64), ("last_commit_seconds", C.c_double), ("last_bvh_seconds", C.c_double),
+                ("d_nodes", C.c_void_p), ("d_tris", C.c_void_p), ("d_shade", C.c_void_p)]
+
+
 FLAG_COUNT = 1
 FLAG_RUSSIAN_ROULETTE = 2
 
@@ -72,7 +79,7 @@ EXPORTS = [
     "ptamd_scene_object_count", "ptamd_scene_add_sphere", "ptamd_scene_add_box", "ptamd_scene_add_mesh",
     "ptamd_scene_add_mesh_file", "ptamd_scene_set_transform", "ptamd_scene_set_radius",
     "ptamd_scene_set_material", "ptamd_scene_set_mesh_group", "ptamd_scene_set_background", "ptamd_scene_set_skybox",
-    "ptamd_scene_commit", "ptamd_model_load", "ptamd_model_load_ex", "ptamd_model_desc", "ptamd_model_group_name", "ptamd_model_free",
+    "ptamd_scene_commit", "ptamd_scene_get_info", "ptamd_model_load", "ptamd_model_load_ex", "ptamd_model_desc", "ptamd_model_group_name", "ptamd_model_free",
     "ptamd_film_create", "ptamd_film_create_external", "ptamd_film_destroy", "ptamd_film_resize",
     "ptamd_film_reset", "ptamd_film_size", "ptamd_film_read", "ptamd_film_average",
     "ptamd_film_resolve_rgba8", "ptamd_film_device_ptrs", "ptamd_render", "ptamd_render_tiles", "ptamd_render_stats", "ptamd_render_counted_noalloc",
@@ -118,6 +125,7 @@ def lib():
         L.ptamd_scene_set_background.argtypes = [vp, f3]
         L.ptamd_scene_set_skybox.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.c_float]
         L.ptamd_scene_commit.argtypes = [vp]
+        L.ptamd_scene_get_info.argtypes = [vp, C.POINTER(CSceneInfo)]
         L.ptamd_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.ptamd_model_load_ex.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(vp)]
         L.ptamd_model_desc.argtypes = [vp, C.POINTER(CMeshDesc)]
@@ -386,6 +394,12 @@ class PathTracer:
 
     def Commit(self):
         check(lib().ptamd_scene_commit(self._h))
+
+    def Info(self):
+        """Upload-path diagnostics (ptamd_scene_get_info) as a dict."""
+        i = CSceneInfo()
+        check(lib().ptamd_scene_get_info(self._h, C.byref(i)))
+        return {n: getattr(i, n) for n, _ in CSceneInfo._fields_}
 
     def ClosestHits(self, rays):
         """Closest-hit records (PathTracer.cpp:38-57) for an (N,6) ray array."""
