@@ -339,8 +339,9 @@ def test_wide_nodes_agree_with_binary_nodes(gpu, monkeypatch):
             film = gpu.Film(w, h)
             gpu.Render(cam, pt, film, 3, 6, seed=31, count=True)
             out.append((hits, cnt, film.Accum(), gpu.RenderStats()))
+            assert (pt.Info()["wide_nodes"] > 0) == (faces == "1")  # the wide walk really ran, or really did not
         (hb, cb, fb, sb), (hw, cw, fw, sw) = out
-        assert cw[:, 0].sum() < 0.7 * cb[:, 0].sum()  # far fewer node visits: the wide walk really ran
+        assert cw[:, 0].sum() < 0.9 * cb[:, 0].sum()  # fewer node visits, work sharing's speculation included
         assert (hb[:, 0] == hw[:, 0]).mean() >= 0.9995
         hit = (hb[:, 0] == 1) & (hw[:, 0] == 1)
         same = hit & (np.abs(hb[:, 1] - hw[:, 1]) <= 1e-6 * np.abs(hb[:, 1]))
