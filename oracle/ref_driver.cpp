@@ -263,11 +263,25 @@ int ModeFilm(int argc, char** argv)
     return 0;
 }
 
+int ModeImages(int argc, char** argv)
+{
+    if (argc < 4) return 2;
+    ModelLoader loader{ std::string(argv[2]) };
+    std::string out = argv[3];
+    std::ofstream list(out + ".txt");
+    int i = 0;
+    for (const auto& im : loader.GetEmbeddedImages()) {
+        list << im.width << " " << im.height << " " << im.channels << "\n";
+        WriteFile((out + "." + std::to_string(i++) + ".u8").c_str(), im.data.data(), im.data.size());
+    }
+    return 0;
+}
+
 } // namespace
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { std::fprintf(stderr, "usage: ref_oracle render|rays|hits|film ...\n"); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: ref_oracle render|rays|hits|film|images ...\n"); return 2; }
     std::string mode = argv[1];
     int rc = 2;
     try {
@@ -275,6 +289,7 @@ int main(int argc, char** argv)
         else if (mode == "rays") rc = ModeRays(argc, argv);
         else if (mode == "hits") rc = ModeHits(argc, argv);
         else if (mode == "film") rc = ModeFilm(argc, argv);
+        else if (mode == "images") rc = ModeImages(argc, argv);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "ref_oracle: exception: %s\n", e.what());
         return 3;

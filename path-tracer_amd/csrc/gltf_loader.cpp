@@ -170,7 +170,7 @@ uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1
 void decode_png_rgba(const uint8_t* data, size_t size, int& w, int& h, std::vector<uint8_t>& rgba)
 {
     static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
-    if (size < 8 || std::memcmp(data, sig, 8)) throw std::runtime_error("image: only PNG images are supported");
+    if (size < 8 || std::memcmp(data, sig, 8)) throw std::runtime_error("image: only PNG and JPEG images are supported");
     size_t pos = 8;
     std::vector<uint8_t> idat, plte, trns;
     int depth = 0, ctype = 0, interlace = 0;
@@ -228,6 +228,18 @@ void decode_png_rgba(const uint8_t* data, size_t size, int& w, int& h, std::vect
         case 6: o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; break;
         }
     }
+}
+
+} // namespace
+bool looks_like_jpeg(const uint8_t* data, size_t size);
+void decode_jpeg_rgba(const uint8_t* data, size_t size, int& w, int& h, std::vector<uint8_t>& rgba); // jpeg_decode.cpp
+namespace {
+// An image of a model file as RGBA8: PNG or JPEG by signature (stb_image, which decodes for the reference, sniffs the
+// same way; its other formats -- BMP, GIF, PSD, PIC, PNM, HDR, TGA -- are not glTF image formats and are refused).
+void decode_image_rgba(const uint8_t* data, size_t size, int& w, int& h, std::vector<uint8_t>& rgba)
+{
+    if (looks_like_jpeg(data, size)) decode_jpeg_rgba(data, size, w, h, rgba);
+    else decode_png_rgba(data, size, w, h, rgba);
 }
 
 struct Doc {
@@ -377,7 +389,7 @@ static void load_any(const std::string& path, Model& out, uint32_t flags)
             }
             int w = 0, h = 0;
             std::vector<uint8_t> rgba;
-            decode_png_rgba(raw.data(), raw.size(), w, h, rgba);
+            decode_image_rgba(raw.data(), raw.size(), w, h, rgba);
             out.image_data.push_back(std::move(rgba));
             ptamd_image pi; pi.width = w; pi.height = h; pi.channels = 4; pi.data = nullptr;
             out.images.push_back(pi);
@@ -598,7 +610,7 @@ std::vector<ObjMaterial> load_mtl(const std::string& path, Model& out)
             std::string file; in >> file;
             std::vector<uint8_t> raw = read_file(dir_of(path) + "/" + file);
             int w = 0, h = 0; std::vector<uint8_t> rgba;
-            decode_png_rgba(raw.data(), raw.size(), w, h, rgba);
+            decode_image_rgba(raw.data(), raw.size(), w, h, rgba);
             out.image_data.push_back(std::move(rgba));
             ptamd_image pi; pi.width = w; pi.height = h; pi.channels = 4; pi.data = nullptr;
             out.images.push_back(pi);

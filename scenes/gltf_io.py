@@ -87,7 +87,8 @@ def write_glb(path, primitives, materials, images=None, nodes=None, scene_nodes=
     """primitives: list of dicts {positions (V,3) f32, normals (V,3) f32|None, uvs (V,2) f32|None,
     indices (T*3,) u32, material: index|None}; each primitive becomes its own glTF mesh.
     materials: list of glTF material dicts (already in glTF JSON form, textures by image index are
-    wired here: any {"index": i} refers to textures[i] == images[i]).  images: list of (H,W,C) uint8.
+    wired here: any {"index": i} refers to textures[i] == images[i]).  images: list of (H,W,C) uint8 arrays (stored as
+    PNG) or of encoded PNG / JPEG files as bytes (stored as they are).
     nodes / scene_nodes: an explicit scene graph in glTF JSON form (node dicts with mesh / children / matrix or
     translation, rotation, scale; root indices); by default one untransformed node per mesh."""
     blob = bytearray()
@@ -138,8 +139,11 @@ def write_glb(path, primitives, materials, images=None, nodes=None, scene_nodes=
     if images:
         doc["images"], doc["textures"], doc["samplers"] = [], [], [{}]
         for img in images:
-            png = np.frombuffer(png_encode(img), dtype=np.uint8)
-            doc["images"].append({"bufferView": add_view(png), "mimeType": "image/png"})
+            if isinstance(img, (bytes, bytearray)):  # an encoded file as it is (JPEG by its signature, else PNG)
+                raw, mime = bytes(img), "image/jpeg" if bytes(img[:2]) == b"\xff\xd8" else "image/png"
+            else:
+                raw, mime = png_encode(img), "image/png"
+            doc["images"].append({"bufferView": add_view(np.frombuffer(raw, dtype=np.uint8)), "mimeType": mime})
             doc["textures"].append({"source": len(doc["images"]) - 1, "sampler": 0})
     while len(blob) % 4:
         blob.append(0)
@@ -216,7 +220,7 @@ def load_gltf(path):
         raise RuntimeError("Model only supports .glb/.gltf: " + path)  # ModelLoader.h:142
     doc, buffers, base = _read_doc(path)
     images = []
-    for img in doc.get("images", []):
+    for img_index, img in enumerate(doc.get("images", [])):
         if "bufferView" in img:
             v = doc["bufferViews"][img["bufferView"]]
             raw = bytes(buffers[v["buffer"]][v.get("byteOffset", 0):v.get("byteOffset", 0) + v["byteLength"]])
@@ -224,6 +228,14 @@ def load_gltf(path):
             raw = base64.b64decode(img["uri"].split(",", 1)[1])
         else:
             raw = open(os.path.join(base, img["uri"]), "rb").read()
+        if raw[:2] == b"\xff\xd8":
+            # JPEG: this Python reader has no decoder for it (and an independent one would not reproduce the reference's
+            # texels bit for bit); the texels that the reference's own loader decoded are kept next to the model
+            side = os.path.splitext(path)[0] + ".images.npz"
+            if not os.path.exists(side):
+                raise RuntimeError("JPEG image in %s: decoded texels expected in %s" % (path, side))
+            images.append(np.load(side)["image_%d" % img_index])
+            continue
         px = png_decode(raw)
         # tinygltf asks stb_image for 4 channels whatever the file holds (tiny_gltf.h:2653)
         h, w, c = px.shape

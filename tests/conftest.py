@@ -43,6 +43,8 @@ def golden_scenes(dragon_field_glb):
                                      mesh_scale=(1.1, 0.9, 1.0)), 8),
         "textured": (presets.mixed("tests/golden/textured.glb", 96, 96, mesh_pos=(2.7, 1.6, 2.6), mesh_rot=(0.0, 25.0, 0.0),
                                    mesh_scale=(1.4, 1.4, 1.4)), 6),
+        "textured_jpeg": (presets.mixed("tests/golden/textured_jpeg.glb", 96, 96, mesh_pos=(2.7, 1.6, 2.6), mesh_rot=(0.0, 25.0, 0.0),
+                                        mesh_scale=(1.4, 1.4, 1.4)), 6),
         "mesh_cornell_128x72": (presets.mesh_cornell("tests/golden/cornell_mesh.glb", 128, 72), 8),
     }
 

@@ -63,6 +63,96 @@ def write_textured_glb(path):
     gltf_io.write_glb(path, [p0, p1, p2], mats, images)
 
 
+def jpeg_pictures():
+    """Small JPEG files (PIL / libjpeg encodes; only the decoder is under test) that between them use every path of the
+    decoder: baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0, sizes that are not multiples of the MCU, one-pixel rows and
+    columns, grey, CMYK, restart intervals, optimised Huffman tables."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(3)
+
+    def picture(w, h):
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.zeros((h, w, 3), np.float64)
+        a[..., 0] = 128 + 100 * np.sin(xx * 0.37) * np.cos(yy * 0.21)
+        a[..., 1] = (xx * 7 + yy * 3) % 256
+        a[..., 2] = 255 * ((xx // 5 + yy // 3) % 2)
+        return np.clip(a + rng.normal(0, 12, a.shape), 0, 255).astype(np.uint8)
+    cases = [(40, 24, "RGB", dict(quality=90, subsampling=0)), (17, 13, "RGB", dict(quality=35, subsampling=1)),
+             (33, 19, "RGB", dict(quality=75, subsampling=2)), (1, 1, "RGB", dict(quality=90, subsampling=2)),
+             (9, 40, "RGB", dict(quality=60, subsampling=2, progressive=True)), (33, 1, "RGB", dict(quality=90, subsampling=1, progressive=True)),
+             (48, 32, "RGB", dict(quality=85, subsampling=0, progressive=True, optimize=True)), (50, 31, "L", dict(quality=80)),
+             (50, 31, "L", dict(quality=60, progressive=True)), (48, 32, "RGB", dict(quality=50, subsampling=1, restart_marker_blocks=3)),
+             (48, 32, "RGB", dict(quality=50, subsampling=2, progressive=True, restart_marker_rows=1)), (31, 29, "RGB", dict(quality=100, subsampling=0)),
+             (40, 24, "CMYK", dict(quality=80))]
+    out = []
+    for w, h, mode, kw in cases:
+        im = Image.fromarray(picture(w, h))
+        im = im.convert(mode) if mode != "RGB" else im
+        buf = io.BytesIO()
+        im.save(buf, "JPEG", **kw)
+        out.append(buf.getvalue())
+    return out
+
+
+def reference_images(glb):
+    """The texels ModelLoader holds after loading glb (ref_oracle images): list of (H, W, C) uint8."""
+    import subprocess
+    import tempfile
+    pre = os.path.join(tempfile.mkdtemp(prefix="ptimg_"), "im")
+    subprocess.run([po.REF_BIN, "images", glb, pre], check=True, capture_output=True)
+    out = []
+    for i, line in enumerate(open(pre + ".txt")):
+        w, h, c = map(int, line.split())
+        out.append(np.fromfile("%s.%d.u8" % (pre, i), np.uint8).reshape(h, w, c))
+    return out
+
+
+def write_jpeg_fixtures():
+    """jpeg_cases.npz: JPEG files + the reference's decode of each. textured_jpeg.glb: the textured test mesh with its
+    base-colour and emissive maps as JPEG (4:2:0 baseline, 4:4:4 progressive), + textured_jpeg.images.npz: the
+    reference's decode of its images, which the Python glTF reader (CPU oracle side) uses in place of a JPEG decoder."""
+    import io
+    import tempfile
+    from PIL import Image
+    files = jpeg_pictures()
+    prim = gltf_io.box_primitive((0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    mat = gltf_io.gltf_material("m", presets.material())
+    tmp = os.path.join(tempfile.mkdtemp(prefix="ptjpg_"), "cases.glb")
+    gltf_io.write_glb(tmp, [prim], [mat], files)
+    dec = reference_images(tmp)
+    assert len(dec) == len(files)
+    np.savez_compressed(os.path.join(HERE, "jpeg_cases.npz"), **{"file_%d" % i: np.frombuffer(f, np.uint8) for i, f in enumerate(files)},
+                        **{"texels_%d" % i: d for i, d in enumerate(dec)})
+    # the textured scene with JPEG maps
+    n = 32
+    yy, xx = np.mgrid[0:n, 0:n]
+    base = np.zeros((n, n, 3), np.uint8)
+    base[..., 0] = 60 + 6 * xx; base[..., 1] = 40 + 6 * yy; base[..., 2] = 128 + (100 * np.sin(xx * 0.5) * np.cos(yy * 0.4)).astype(int)
+    em = np.zeros((n, n, 3), np.uint8)
+    em[(xx % 8 < 2) & (yy % 8 < 2)] = (255, 180, 90)
+
+    def jpg(a, **kw):
+        b = io.BytesIO()
+        Image.fromarray(a).save(b, "JPEG", **kw)
+        return b.getvalue()
+    rng = np.random.default_rng(5)
+    mr = np.zeros((16, 16, 3), np.uint8)
+    mr[..., 1] = rng.integers(20, 255, (16, 16)); mr[..., 2] = 128
+    images = [jpg(base, quality=88, subsampling=2), mr, jpg(em, quality=92, subsampling=0, progressive=True)]
+    p0 = gltf_io.bumpy_sphere_primitive(24, 32, radius=0.8, bump=0.05, freq=3, material_index=0)
+    p0["uvs"] = p0["uvs"] * np.array([2.0, 1.5], np.float32)
+    p1 = gltf_io.box_primitive((1.2, -0.3, 0.2), (10.0, 20.0, 0.0), (0.7, 0.7, 0.7), 1)
+    mats = [{"name": "jpeg_pbr", "emissiveFactor": [1.2, 1.2, 1.2],
+             "pbrMetallicRoughness": {"baseColorFactor": [1.0, 0.9, 1.0, 1.0], "baseColorTexture": {"index": 0}, "metallicFactor": 0.6,
+                                      "roughnessFactor": 0.8, "metallicRoughnessTexture": {"index": 1}},
+             "emissiveTexture": {"index": 2}},
+            {"name": "jpeg_plain", "pbrMetallicRoughness": {"baseColorFactor": [1, 1, 1, 1], "baseColorTexture": {"index": 0}, "metallicFactor": 0.0}}]
+    glb = os.path.join(HERE, "textured_jpeg.glb")
+    gltf_io.write_glb(glb, [p0, p1], mats, images)
+    np.savez_compressed(os.path.join(HERE, "textured_jpeg.images.npz"), **{"image_%d" % i: d for i, d in enumerate(reference_images(glb))})
+
+
 def dragon_scenes(field_glb):
     """The reference's own 100 000-triangle model (tests/golden/chinese_dragon.glb is a byte copy of its
     assets/models/chinese_dragon.glb) alone under the constant background, and the ten-instance field derived from
@@ -106,7 +196,12 @@ def main():
     import tempfile
     field = os.path.join(tempfile.mkdtemp(prefix="ptgold_"), "dragon_field.glb")
     dragon.write_dragon_field(field)
-    scenes = dict(golden_scenes() if not only or any(n not in ("dragon", "dragon_field") for n in only) else {}, **dragon_scenes(field))
+    if not only or "textured_jpeg" in only:
+        write_jpeg_fixtures()
+    late = {"textured_jpeg": (presets.mixed("tests/golden/textured_jpeg.glb", 96, 96, mesh_pos=(2.7, 1.6, 2.6), mesh_rot=(0.0, 25.0, 0.0),
+                                            mesh_scale=(1.4, 1.4, 1.4)), 6)}
+    late.update(dragon_scenes(field))
+    scenes = dict(golden_scenes() if not only or any(n not in late for n in only) else {}, **late)
     for name, (scene, depth) in scenes.items():
         if only and name not in only:
             continue

@@ -20,7 +20,7 @@ from conftest import lum, rmse
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
-NAMES = ["sphere_cornell", "glass_mirror", "box_cornell", "mesh_cornell", "blob_mixed", "textured", "dragon", "dragon_field"]
+NAMES = ["sphere_cornell", "glass_mirror", "box_cornell", "mesh_cornell", "blob_mixed", "textured", "textured_jpeg", "dragon", "dragon_field"]
 
 
 @pytest.fixture(scope="module")

@@ -179,3 +179,37 @@ def test_deeply_nested_json_and_short_png_header_are_refused(tmp_path):
     open(path, "w").write(json.dumps(doc))
     with pytest.raises(ptamd.PtamdError, match="PNG"):
         ptamd.load_model(path)
+
+
+def test_jpeg_images_decode_to_the_reference_texels(tmp_path):
+    """JPEG-encoded glTF images (the reference takes them through stb_image): thirteen files covering baseline and
+    progressive coding, 4:4:4 / 4:2:2 / 4:2:0, ragged sizes, one-pixel rows and columns, grey, CMYK, restart intervals
+    and optimised tables must decode to exactly the RGBA texels the reference's loader holds (tests/golden/
+    jpeg_cases.npz, written by make_golden.py from the reference itself), as must the maps of textured_jpeg.glb."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "jpeg_cases.npz"))
+    n = sum(1 for k in g.files if k.startswith("file_"))
+    assert n == 13
+    prim = gltf_io.box_primitive((0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    mat = gltf_io.gltf_material("m", [1, 1, 1, 1.0, 0.0, 1, 1, 1, 0.0, 1.5, 0.0])
+    path = str(tmp_path / "cases.glb")
+    gltf_io.write_glb(path, [prim], [mat], [g["file_%d" % i].tobytes() for i in range(n)])
+    got = ptamd.load_model(path)["images"]
+    assert len(got) == n
+    for i in range(n):
+        want = g["texels_%d" % i]
+        assert want.shape[2] == 4 and got[i].shape == want.shape and np.array_equal(got[i], want), i
+    side = np.load(os.path.join(GOLDEN, "textured_jpeg.images.npz"))
+    got = ptamd.load_model(os.path.join(GOLDEN, "textured_jpeg.glb"))["images"]
+    assert len(got) == 3
+    for i in range(3):
+        assert np.array_equal(got[i], side["image_%d" % i])
+    # truncated and corrupt files end in a clean error or a partial picture, never a crash
+    raw = g["file_4"].tobytes()
+    for cut in (3, 20, len(raw) // 2, len(raw) - 2):
+        gltf_io.write_glb(path, [prim], [mat], [raw[:cut]])
+        try:
+            ptamd.load_model(path)
+        except ptamd.PtamdError as e:
+            assert "JPEG" in str(e) or "image" in str(e)
