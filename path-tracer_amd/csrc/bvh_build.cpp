@@ -1,10 +1,12 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <unordered_map>
 
 namespace ptamd {
@@ -32,22 +34,38 @@ constexpr uint32_t kSweepMax = 128;
 uint32_t kLeafMax = 2;
 float kCostNode = 1.0f, kCostTri = 1.2f;
 
+// What a subtree build writes: its own nodes and leaf slots (indices local to it until they are merged).
+struct TreeOut {
+    std::vector<uint32_t> slots;    // leaf order -> face
+    std::vector<DNode> nodes;
+    int depthSeen = 0;
+    std::vector<uint32_t> order; std::vector<float> rightArea; // scratch of the exact sweeps
+};
+
+// Subtrees of at least this many primitives are handed to worker threads when the mesh is large: the top of the tree is
+// built by the calling thread, which leaves a placeholder where such a subtree hangs.
+constexpr uint32_t kParallelMin = 1u << 16;   // meshes below this size are built by one thread
+constexpr uint32_t kTaskPrims = 1u << 13;     // subtree size at which a task is cut off
+
 struct Builder {
     std::vector<Box3> fb;
     std::vector<float> fc; // 3 per face
-    std::vector<uint32_t> idx;      // primitive indices, permuted by the build
+    std::vector<uint32_t> idx;      // primitive indices, permuted by the build (a subtree only touches its own range)
     std::vector<uint32_t> primA, primB; // faces of each primitive (primB = kNone for a lone triangle)
-    std::vector<uint32_t> slots;    // leaf order -> face
-    std::vector<DNode> nodes;
     int maxDepth = 32;
-    int depthSeen = 0;
     float pad = 0.f;
+    struct Task { uint32_t start, count; int depth; int32_t parent; bool right; TreeOut out; int32_t ref; };
+    std::vector<Task> tasks;        // deferred subtrees (filled only while `defer` is set)
+    bool defer = false;
 
     static int ceil_log2(uint32_t n) { int l = 0; while ((1u << l) < n) ++l; return l; }
 
-    // Returns the child reference for faces idx[start, start+count); bounds -> out.
-    int32_t build(uint32_t start, uint32_t count, int depth, Box3& out)
+    // Returns the child reference for faces idx[start, start+count); bounds -> out. Nodes and leaf slots go to T.
+    // parent / right: where the reference will be stored (used when the subtree is deferred to a task).
+    int32_t build(TreeOut& T, uint32_t start, uint32_t count, int depth, Box3& out, int32_t parent = -1, bool right = false)
     {
+        std::vector<uint32_t>& slots = T.slots; std::vector<DNode>& nodes = T.nodes; int& depthSeen = T.depthSeen;
+        (void)slots;
         Box3 b; b.reset();
         Box3 cb; cb.reset();
         for (uint32_t i = start; i < start + count; ++i) {
@@ -57,7 +75,11 @@ struct Builder {
         out = b;
         const int remaining = maxDepth - depth; // inner levels still available below this one, this one included: remaining + 0
         bool forceMedian = ceil_log2(count) >= remaining; // keep enough levels for a balanced finish
-        if (count == 1 || (count <= kLeafMax && (remaining <= 0 || forceMedian))) return leaf(start, count);
+        if (count == 1 || (count <= kLeafMax && (remaining <= 0 || forceMedian))) return leaf(T, start, count);
+        if (defer && count <= kTaskPrims && parent >= 0) { // a worker thread builds this subtree; its box is known already
+            tasks.push_back(Task{ start, count, depth, parent, right, TreeOut(), 0 });
+            return 0x7ffffffe; // patched when the tasks are merged
+        }
 
         // Split search. Ranges of up to kSweepMax primitives: exact sweep over the centroid order of each axis (every
         // split position is a candidate); larger ranges: kBins centroid bins per axis.
@@ -66,12 +88,12 @@ struct Builder {
         float bestCost = std::numeric_limits<float>::max();
         const bool sweep = count <= kSweepMax;
         if (!forceMedian && sweep) {
-            std::vector<uint32_t> order(count);
-            std::vector<float> rightArea(count);
+            std::vector<uint32_t>& order = T.order; std::vector<float>& rightArea = T.rightArea;
+            if (order.size() < count) { order.resize(kSweepMax); rightArea.resize(kSweepMax); }
             for (int axis = 0; axis < 3; ++axis) {
                 if (!(cb.hi[axis] - cb.lo[axis] > 0.f)) continue;
                 for (uint32_t i = 0; i < count; ++i) order[i] = idx[start + i];
-                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c2) {
+                std::sort(order.begin(), order.begin() + count, [&](uint32_t a, uint32_t c2) {
                     const float ca = fc[3 * (size_t)a + axis], cc = fc[3 * (size_t)c2 + axis];
                     return ca < cc || (ca == cc && a < c2);
                 });
@@ -112,9 +134,9 @@ struct Builder {
             if (bestAxis >= 0) {
                 float parentArea = std::max(b.area(), 1e-30f);
                 float splitCost = kCostNode + kCostTri * bestCost / parentArea;
-                if (count <= kLeafMax && kCostTri * (float)count <= splitCost) return leaf(start, count);
+                if (count <= kLeafMax && kCostTri * (float)count <= splitCost) return leaf(T, start, count);
             } else if (count <= kLeafMax) {
-                return leaf(start, count);
+                return leaf(T, start, count);
             }
         }
         uint32_t mid;
@@ -146,8 +168,8 @@ struct Builder {
         nodes.emplace_back();
         depthSeen = std::max(depthSeen, depth + 1);
         Box3 lb, rb;
-        int32_t l = build(start, mid - start, depth + 1, lb);
-        int32_t r = build(mid, start + count - mid, depth + 1, rb);
+        int32_t l = build(T, start, mid - start, depth + 1, lb, me, false);
+        int32_t r = build(T, mid, start + count - mid, depth + 1, rb, me, true);
         DNode& n = nodes[(size_t)me];
         std::memset(&n, 0, sizeof n);
         pad_box(lb); pad_box(rb);
@@ -162,8 +184,9 @@ struct Builder {
         for (int k = 0; k < 3; ++k) { b.lo[k] -= pad; b.hi[k] += pad; }
     }
     static constexpr uint32_t kNone = 0xFFFFFFFFu;
-    int32_t leaf(uint32_t start, uint32_t count)
+    int32_t leaf(TreeOut& T, uint32_t start, uint32_t count)
     {
+        std::vector<uint32_t>& slots = T.slots;
         uint32_t first = (uint32_t)slots.size(), mask = 0;
         for (uint32_t i = 0; i < count; ++i) {
             uint32_t p = idx[start + i];
@@ -185,8 +208,9 @@ namespace {
 void pair_quads(const float* P, const int32_t* group, uint32_t n, std::vector<uint32_t>& primA, std::vector<uint32_t>& primB,
                 std::vector<int>& rotation)
 {
+    // Edge table: one record per (face, edge) holding a 64-bit hash of the edge's two end points (unordered) and
+    // face * 4 + edge, sorted by hash; the faces on an edge are the records of equal hash whose end points really match.
     struct Key { uint32_t v[6]; bool operator==(const Key& o) const { return !std::memcmp(v, o.v, sizeof v); } };
-    struct KeyHash { size_t operator()(const Key& k) const { size_t h = 1469598103934665603ull; for (uint32_t x : k.v) h = (h ^ x) * 1099511628211ull; return h; } };
     auto key_of = [&](const float* p, const float* q) {
         Key k; uint32_t a[3], b[3];
         std::memcpy(a, p, 12); std::memcpy(b, q, 12);
@@ -194,10 +218,15 @@ void pair_quads(const float* P, const int32_t* group, uint32_t n, std::vector<ui
         std::memcpy(k.v, a, 12); std::memcpy(k.v + 3, b, 12);
         return k;
     };
-    std::unordered_map<Key, std::vector<uint32_t>, KeyHash> edges;
-    edges.reserve((size_t)n * 3);
+    auto hash_of = [](const Key& k) { uint64_t h = 1469598103934665603ull; for (uint32_t x : k.v) h = (h ^ x) * 1099511628211ull; return h ^ (h >> 29); };
+    auto edge_key = [&](uint32_t f, int e) { return key_of(P + 9 * (size_t)f + 3 * e, P + 9 * (size_t)f + 3 * ((e + 1) % 3)); };
+    struct Rec { uint64_t h; uint32_t id; };
+    std::vector<Rec> recs((size_t)n * 3);
     for (uint32_t f = 0; f < n; ++f)
-        for (int e = 0; e < 3; ++e) edges[key_of(P + 9 * (size_t)f + 3 * e, P + 9 * (size_t)f + 3 * ((e + 1) % 3))].push_back(f);
+        for (int e = 0; e < 3; ++e) recs[(size_t)f * 3 + e] = Rec{ hash_of(edge_key(f, e)), f * 4u + (uint32_t)e };
+    std::sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.h < y.h || (x.h == y.h && x.id < y.id); });
+    std::vector<uint32_t> where((size_t)n * 3); // (face, edge) -> its place in the sorted table: the other faces on the edge sit next to it
+    for (size_t i = 0; i < recs.size(); ++i) where[(size_t)(recs[i].id >> 2) * 3 + (recs[i].id & 3u)] = (uint32_t)i;
     std::vector<char> used(n, 0);
     rotation.assign(n, 0);
     for (uint32_t f = 0; f < n; ++f) {
@@ -207,10 +236,13 @@ void pair_quads(const float* P, const int32_t* group, uint32_t n, std::vector<ui
         for (int e = 0; e < 3 && partner == Builder::kNone; ++e) {
             // edge (b, c) = vertices (e, e+1); a = vertex e+2
             const float* b = P + 9 * (size_t)f + 3 * e; const float* c = P + 9 * (size_t)f + 3 * ((e + 1) % 3); const float* a = P + 9 * (size_t)f + 3 * ((e + 2) % 3);
-            auto it = edges.find(key_of(b, c));
-            if (it == edges.end()) continue;
-            for (uint32_t g : it->second) {
-                if (g == f || used[g] || (group && group[g] != group[f])) continue;
+            const Key bc = key_of(b, c);
+            const uint64_t h = hash_of(bc);
+            size_t first = where[(size_t)f * 3 + e];
+            while (first > 0 && recs[first - 1].h == h) --first;
+            for (auto it = recs.begin() + (long)first; it != recs.end() && it->h == h && partner == Builder::kNone; ++it) {
+                const uint32_t g = it->id >> 2;
+                if (g == f || used[g] || (group && group[g] != group[f]) || !(edge_key(g, (int)(it->id & 3u)) == bc)) continue;
                 // the vertex of g that is neither b nor c
                 const float* d = nullptr;
                 for (int k = 0; k < 3; ++k) {
@@ -228,7 +260,6 @@ void pair_quads(const float* P, const int32_t* group, uint32_t n, std::vector<ui
                 for (int k = 0; k < 3; ++k) ok = ok && std::fabs(d[k] - (b[k] + c[k] - a[k])) <= tol;
                 if (!ok) continue;
                 partner = g; rot = (e + 2) % 3; // A is used with `a` as its first vertex
-                break;
             }
         }
         primA.push_back(f); primB.push_back(partner); rotation[f] = rot;
@@ -282,12 +313,46 @@ BvhResult build_bvh(const float* P, const int32_t* group, uint32_t n, int max_de
     // Child boxes are padded so that the fused-multiply-add slab test of the kernels never culls a
     // triangle an exact (b - o) / d test would keep (its rounding error is ~1e-7 of the coordinates).
     b.pad = 2e-6f * std::max(scale, 1e-20f);
-    b.nodes.reserve(np); b.slots.reserve(n);
+    TreeOut top;
+    top.nodes.reserve(np); top.slots.reserve(n);
     Box3 rootBounds;
-    res.root = np ? b.build(0, np, 0, rootBounds) : ~0;
-    res.nodes = std::move(b.nodes);
-    res.order = std::move(b.slots);
-    res.depth = b.depthSeen;
+    b.defer = np >= kParallelMin && !std::getenv("PTAMD_BVH_THREADS_OFF");
+    res.root = np ? b.build(top, 0, np, 0, rootBounds) : ~0;
+    if (!b.tasks.empty()) {
+        // The deferred subtrees are independent (each permutes only its own range of idx): worker threads take them in
+        // turn; then they are appended in task order, which keeps the result the same for any number of threads.
+        b.defer = false;
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        std::atomic<size_t> next{ 0 };
+        auto work = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < b.tasks.size();) {
+                Builder::Task& t = b.tasks[i];
+                Box3 box;
+                t.ref = b.build(t.out, t.start, t.count, t.depth, box);
+            }
+        };
+        for (unsigned i = 1; i < hw; ++i) pool.emplace_back(work);
+        work();
+        for (std::thread& th : pool) th.join();
+        for (Builder::Task& t : b.tasks) {
+            const int32_t nodeOff = (int32_t)top.nodes.size();
+            const uint32_t slotOff = (uint32_t)top.slots.size();
+            auto moved = [&](int32_t ref) { // a reference of the subtree, in the merged arrays
+                if (ref >= 0) return ref + nodeOff;
+                const uint32_t code = ~(uint32_t)ref;
+                return ~(int32_t)((((code >> 6) + slotOff) << 6) | (code & 63u));
+            };
+            for (DNode& nd : t.out.nodes) { nd.left = moved(nd.left); nd.right = moved(nd.right); }
+            top.nodes.insert(top.nodes.end(), t.out.nodes.begin(), t.out.nodes.end());
+            top.slots.insert(top.slots.end(), t.out.slots.begin(), t.out.slots.end());
+            (t.right ? top.nodes[(size_t)t.parent].right : top.nodes[(size_t)t.parent].left) = moved(t.ref);
+            top.depthSeen = std::max(top.depthSeen, t.out.depthSeen);
+        }
+    }
+    res.nodes = std::move(top.nodes);
+    res.order = std::move(top.slots);
+    res.depth = top.depthSeen;
     return res;
 }
 

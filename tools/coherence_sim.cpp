@@ -5,7 +5,7 @@
 // workgroup), records every ray's walk as segments (inner-node steps, then primitives of one leaf), and prices a
 // wave as the while-while loop does: per segment the maximum over its lanes.
 //
-//   g++ -O2 -std=c++17 tools/coherence_sim.cpp path-tracer_amd/csrc/bvh_build.cpp path-tracer_amd/csrc/gltf_loader.cpp -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -lz -o /tmp/coherence_sim
+//   g++ -O2 -std=c++17 tools/coherence_sim.cpp path-tracer_amd/csrc/bvh_build.cpp path-tracer_amd/csrc/gltf_loader.cpp path-tracer_amd/csrc/jpeg_decode.cpp -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -lz -o /tmp/coherence_sim
 //   /tmp/coherence_sim tests/golden/cornell_mesh.glb [blocks] [spp] [block_lanes]
 #include <algorithm>
 #include <cmath>
@@ -113,7 +113,7 @@ struct Lane {
 };
 
 // Instruction prices of one wave-level loop trip (vector instructions, measured on the kernel)
-static const double kNodeTrip = 35.0, kPrimTrip = 40.0;
+static const double kNodeTrip = 38.0, kPrimTrip = 42.0; // loop bookkeeping included
 
 static double wave_cost(const std::vector<const Walk*>& lanes, double* nodeTrips = nullptr, double* primTrips = nullptr)
 {
@@ -165,7 +165,7 @@ int main(int argc, char** argv)
     // rays one after the other; dynamic = a lane that runs out takes the next unstarted ray of the wave's 64 k
     const int KS[4] = { 1, 2, 4, 8 };
     double statCost[4] = { 0 }, dynCost[4] = { 0 }, statRays[4] = { 0 };
-    const double kFetch = 25.0; // instructions of a "next ray" body, paid by every outer iteration in which some lane needs it
+    const double kFetch = 60.0; // instructions of a "next ray" body, paid by every outer iteration in which some lane needs it
     std::vector<std::vector<std::vector<Walk>>> hist; // [round][wave][lane]
     for (int b = 0; b < blocks; ++b) {
         const int block = (int)(U(rng) * (tilesX * tilesY / wavesPerBlock));
@@ -279,6 +279,61 @@ int main(int argc, char** argv)
             }
         }
         printf("k = %d rays per lane and phase: static %.0f instr/wave-ray, dynamic %.0f\n", k, statCost[ki] / statRays[ki] * 64.0, dynCost[ki] / statRays[ki] * 64.0);
+    }
+    // Other schedules of the same walks, simulated lane by lane: a wave owns a queue of 64 k rays; a lane that has
+    // finished its ray takes the next one when a refill happens (cost kFetch, when at least `refillAt` lanes are idle
+    // or nothing else can run). "majority": a trip is a node step for all lanes at inner nodes or a primitive test for
+    // all lanes at leaves, whichever group is larger. "both": every trip issues both bodies.
+    {
+        const int ks[4] = { 1, 2, 4, 8 };
+        for (int mode = 0; mode < 2; ++mode)
+            for (int ki = 0; ki < 4; ++ki)
+                for (int refillAt : { 16, 32 }) {
+                    const int k = ks[ki];
+                    double cost = 0, nrays = 0;
+                    for (size_t r0 = 0; r0 + k <= hist.size() && r0 < 4000; r0 += k)
+                        for (int w = 0; w < wavesPerBlock; ++w) {
+                            std::vector<const Walk*> queue;
+                            for (int j = 0; j < k; ++j) for (int l = 0; l < 64; ++l) queue.push_back(&hist[r0 + j][w][l]);
+                            size_t next = 0;
+                            const Walk* cur[64]; size_t seg[64]; int nLeft[64], pLeft[64];
+                            const Walk* const kWaiting = (const Walk*)1; // finished, waits for a refill
+                            auto load = [&](int l) {
+                                cur[l] = next < queue.size() ? queue[next++] : nullptr; seg[l] = 0;
+                                if (cur[l]) { nLeft[l] = cur[l]->segs[0].nodes; pLeft[l] = cur[l]->segs[0].prims; }
+                            };
+                            auto advance = [&](int l) { // after a step: move to the next segment / finish
+                                while (cur[l] && nLeft[l] == 0 && pLeft[l] == 0) {
+                                    if (++seg[l] >= cur[l]->segs.size()) { cur[l] = kWaiting; break; }
+                                    nLeft[l] = cur[l]->segs[seg[l]].nodes; pLeft[l] = cur[l]->segs[seg[l]].prims;
+                                }
+                            };
+                            for (int l = 0; l < 64; ++l) { load(l); advance(l); }
+                            for (;;) {
+                                int idle = 0, atNode = 0, atLeaf = 0;
+                                for (int l = 0; l < 64; ++l) {
+                                    if (cur[l] == kWaiting || !cur[l]) ++idle;
+                                    else if (nLeft[l] > 0) ++atNode; else ++atLeaf;
+                                }
+                                const bool canRefill = next < queue.size() && idle > 0;
+                                if (atNode + atLeaf == 0 && !canRefill) break;
+                                if (canRefill && (idle >= refillAt || atNode + atLeaf == 0)) {
+                                    for (int l = 0; l < 64; ++l) if (cur[l] == kWaiting || !cur[l]) { load(l); if (cur[l]) advance(l); }
+                                    cost += kFetch;
+                                    continue;
+                                }
+                                if (mode == 0) {
+                                    if (atNode >= atLeaf) { cost += kNodeTrip; for (int l = 0; l < 64; ++l) if (cur[l] > kWaiting && nLeft[l] > 0) { --nLeft[l]; advance(l); } }
+                                    else { cost += kPrimTrip; for (int l = 0; l < 64; ++l) if (cur[l] > kWaiting && nLeft[l] == 0 && pLeft[l] > 0) { --pLeft[l]; advance(l); } }
+                                } else {
+                                    cost += (atNode ? kNodeTrip : 0) + (atLeaf ? kPrimTrip : 0);
+                                    for (int l = 0; l < 64; ++l) if (cur[l] > kWaiting) { if (nLeft[l] > 0) --nLeft[l]; else --pLeft[l]; advance(l); }
+                                }
+                            }
+                            nrays += 64.0 * k;
+                        }
+                    printf("%-8s k = %2d refill at %2d idle: %.0f instr/wave-ray\n", mode == 0 ? "majority" : "both", k, refillAt, cost / nrays * 64.0);
+                }
     }
     printf("rays %.0f, per lane: %.2f nodes, %.2f prims per ray\n", rays, laneNodes / rays, lanePrims / rays);
     const double wavesTotal = rounds * wavesPerBlock;
