@@ -81,7 +81,8 @@ typedef struct ptamd_camera {
 
 typedef struct ptamd_rect { int32_t x0, y0, x1, y1; } ptamd_rect; /* [x0,x1) x [y0,y1), y = 0 is the bottom row */
 
-/* Counters of the last ptamd_render call that passed PTAMD_FLAG_COUNT. */
+/* Counters of the last ptamd_render / ptamd_render_tiles call that passed PTAMD_FLAG_COUNT (each scene tallies into a
+ * buffer of its own; ptamd_render_stats reads the one used last). */
 typedef struct ptamd_stats {
     uint64_t samples; /* paths started (top-level TraceRay calls) */
     uint64_t rays;    /* rays cast, primary + bounces */
@@ -110,7 +111,7 @@ typedef struct ptamd_model ptamd_model;
 /* Selects the HIP device for this process and creates the library's stream.  No reference
  * counterpart (the reference is CPU-only).  Fails with PTAMD_ERR_DEVICE when no GPU is usable:
  * there is no CPU fallback.  One process drives one GPU: a second call must name the same device.
- * The library keeps process-wide state (device, stream, counters); calls that touch the same scene or
+ * The library keeps process-wide state (device, stream); calls that touch the same scene or
  * film handle, or that change the stream, must not overlap (the last-error string is per thread). */
 int ptamd_init(int device);
 /* Use a caller-owned hipStream_t (e.g. PyTorch's current stream) for all later launches, copies and memsets.

@@ -38,7 +38,7 @@ hipStream_t g_stream = nullptr;
 bool g_initialised = false;
 int g_device = -1;
 constexpr int kNumCounters = 10;
-unsigned long long* g_counters = nullptr; // device, kNumCounters x u64 (the fields of ptamd_stats)
+const unsigned long long* g_last_counters = nullptr; // counters of the last counting launch (a scene's own buffer): what ptamd_render_stats reads
 unsigned long long* g_static_counters = nullptr; // the same, in the library's static device array (no allocation behind it)
 
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
@@ -102,6 +102,7 @@ struct ptamd_scene {
     DevBuf<DNode> d_nodes; DevBuf<DWideNode> d_wide; DevBuf<float> d_lds_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
     DevBuf<uint32_t> d_sky; int sky_size = 0; float sky_intensity = 1.0f;
+    unsigned long long* d_counters = nullptr; // this scene's PTAMD_FLAG_COUNT tallies (allocated by its first counting render)
     DScene dscene;
     void release() // what commit rebuilds; the sky map is uploaded by its own call and outlives commits
     {
@@ -298,7 +299,6 @@ int ptamd_init(int device)
     if (g_initialised && device != g_device) return fail(PTAMD_ERR_STATE, "already initialised on another device (one process drives one GPU)");
     PT_HIP(hipSetDevice(device));
     if (!g_own_stream) { PT_HIP(hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking)); g_stream = g_own_stream; }
-    if (!g_counters) PT_HIP(hipMalloc(reinterpret_cast<void**>(&g_counters), kNumCounters * sizeof(unsigned long long)));
     // the statically allocated counters of ptamd_render_counted_noalloc: their address on this device, resolved once here
     PT_HIP(scratch_counters(device, &g_static_counters));
     g_initialised = true; g_device = device;
@@ -335,6 +335,7 @@ int ptamd_scene_destroy(ptamd_scene* s)
 {
     if (!s) return PTAMD_OK;
     s->release(); s->d_sky.release();
+    if (s->d_counters) { if (g_last_counters == s->d_counters) g_last_counters = nullptr; (void)hipFree(s->d_counters); }
     delete s;
     return PTAMD_OK;
 }
@@ -869,7 +870,8 @@ int ptamd_film_device_ptrs(ptamd_film* f, void** a, void** s)
 }
 
 // ------------------------------------------------------------------------------- render
-// counters: where a PTAMD_FLAG_COUNT launch tallies (kNumCounters x u64 of device memory, cleared here first)
+// counters: where a PTAMD_FLAG_COUNT launch tallies (kNumCounters x u64 of device memory, cleared here first); null = the
+// scene's own buffer
 static int render_impl(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
                        int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags,
                        int tile_size, int tile_phase, int tile_stride, unsigned long long* counters)
@@ -886,6 +888,11 @@ static int render_impl(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, u
     rp.x0 = rect ? std::max(0, rect->x0) : 0; rp.y0 = rect ? std::max(0, rect->y0) : 0;
     rp.x1 = rect ? std::min(f->w, rect->x1) : f->w; rp.y1 = rect ? std::min(f->h, rect->y1) : f->h;
     if (flags & PTAMD_FLAG_COUNT) {
+        if (!counters) { // the scene's own counters: two scenes' counting renders do not share tallies
+            if (!s->d_counters) PT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_counters), kNumCounters * sizeof(unsigned long long)));
+            counters = s->d_counters;
+            g_last_counters = counters;
+        }
         PT_HIP(hipMemsetAsync(counters, 0, kNumCounters * sizeof(unsigned long long), g_stream));
         rp.counters = counters;
     }
@@ -911,7 +918,7 @@ static int render_impl(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, u
 int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
                  int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags)
 {
-    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, rect, flags, 0, 0, 0, g_counters);
+    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, rect, flags, 0, 0, 0, nullptr);
 }
 int ptamd_render_counted_noalloc(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
                                  int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags, ptamd_stats* d_stats)
@@ -928,14 +935,15 @@ int ptamd_render_tiles(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, u
 {
     if (tile_size < 8 || tile_size % 8 != 0 || tile_size > 4096) return fail(PTAMD_ERR_ARG, "tile_size must be a multiple of 8 in [8, 4096]");
     if (tile_stride < 1 || tile_phase < 0 || tile_phase >= tile_stride) return fail(PTAMD_ERR_ARG, "need 0 <= tile_phase < tile_stride");
-    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, nullptr, flags, tile_size, tile_phase, tile_stride, g_counters);
+    return render_impl(s, cam, f, spp_begin, spp_count, depth, albedo_only, seed, nullptr, flags, tile_size, tile_phase, tile_stride, nullptr);
 }
 int ptamd_render_stats(ptamd_stats* out)
 {
     if (!out) return fail(PTAMD_ERR_ARG, "null argument");
     if (int rc = need_init()) return rc;
     unsigned long long c[kNumCounters];
-    PT_HIP(hipMemcpyAsync(c, g_counters, sizeof c, hipMemcpyDeviceToHost, g_stream));
+    if (!g_last_counters) return fail(PTAMD_ERR_STATE, "no render with PTAMD_FLAG_COUNT has run (or its scene is gone)");
+    PT_HIP(hipMemcpyAsync(c, g_last_counters, sizeof c, hipMemcpyDeviceToHost, g_stream));
     PT_HIP(hipStreamSynchronize(g_stream));
     out->samples = c[0]; out->rays = c[1]; out->nodes = c[2]; out->tris = c[3];
     out->ray_trips = c[4]; out->node_trips = c[5]; out->tri_trips = c[6]; out->shade_lanes = c[7]; out->shade_trips = c[8]; out->steal_rounds = c[9];

@@ -84,3 +84,21 @@ def test_edits_rewrite_rows_and_leave_geometry_in_place(gpu, dragon_field_glb):
     pt.Commit()
     third = pt.Info()
     assert third["geometry_uploads"] == 2 and third["last_bvh_seconds"] == 0.0 and third["objects"] == before["objects"] + 1
+
+
+def test_counting_renders_of_two_scenes_do_not_share_tallies(gpu):
+    """Each scene counts into a buffer of its own; ptamd_render_stats reports the counting render that ran last, and
+    says so when that scene is gone."""
+    a, cam_a = gpu.build_scene(presets.sphere_cornell(48, 32))
+    b, cam_b = gpu.build_scene(presets.mesh_cornell("tests/golden/cornell_mesh.glb", 40, 24))
+    fa, fb = gpu.Film(48, 32), gpu.Film(40, 24)
+    gpu.Render(cam_a, a, fa, 3, 4, count=True)
+    gpu.Render(cam_b, b, fb, 2, 4, count=True)
+    sb = gpu.RenderStats()
+    assert sb["samples"] == 40 * 24 * 2 and sb["nodes"] > 0
+    gpu.Render(cam_a, a, fa, 3, 4, spp_begin=3, count=True)
+    sa = gpu.RenderStats()
+    assert sa["samples"] == 48 * 32 * 3 and sa["nodes"] == 0  # spheres and boxes only: no tree was walked
+    a.close()
+    with pytest.raises(gpu.PtamdError, match="PTAMD_FLAG_COUNT"):
+        gpu.RenderStats()
