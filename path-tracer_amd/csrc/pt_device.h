@@ -39,6 +39,15 @@ PT_DEV uint32_t path_key(uint32_t seed_hash, uint32_t pixel, uint32_t sample)
     uint32_t k = pcg_hash(seed_hash ^ pixel);
     return pcg_hash(k + sample * 0x9E3779B9u);
 }
+constexpr uint32_t kDrawStep = 0x9E3779B9u;
+// The same value from a running counter: ctr = (bounce * 8 + draw + 1) * kDrawStep, advanced by kDrawStep per draw, so
+// that a bounce costs one multiply and each draw an add and an exclusive-or.
+PT_DEV uint32_t draw_counter(uint32_t bounce) { return (bounce * 8u + 1u) * kDrawStep; }
+PT_DEV float rand01c(uint32_t key, uint32_t ctr)
+{
+    uint32_t r = pcg_hash(key ^ ctr);
+    return (float)(r >> 8) * 5.9604644775390625e-8f;
+}
 PT_DEV float rand01(uint32_t key, uint32_t bounce, uint32_t draw)
 {
     uint32_t r = pcg_hash(key ^ ((bounce * 8u + draw + 1u) * 0x9E3779B9u));
@@ -638,8 +647,9 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
             if (t >= 0.0f && t < best.t) { best.t = t; best.obj = i; }
         } else {
             const DMesh& me = sc.meshes[ob.mesh];
-            f3 oo = xform_point(me.minv, ray.o);
-            f3 dd = xform_dir(me.minv, ray.d);
+            const bool identity = (me.flags & 8u) != 0u; // wave-uniform: multiplying by the identity returns its argument exactly
+            f3 oo = identity ? ray.o : xform_point(me.minv, ray.o);
+            f3 dd = identity ? ray.d : xform_dir(me.minv, ray.d);
             float len2 = dot(dd, dd);
             const bool valid = len2 != 0.0f;       // Mesh.cpp:64
             if (!COOP && !valid) continue;
@@ -760,7 +770,8 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
         f3 pObj = (pa * w + pb * u) + pc * v;
         f3 nObj = normalize((na * w + nb * u) + nc * v);
         float tu = w * s4.z + u * s5.x + v * s5.z, tv = w * s4.w + u * s5.y + v * s5.w;
-        p = xform_point(me.m, pObj);
+        const bool identity = (me.flags & 8u) != 0u;
+        p = identity ? pObj : xform_point(me.m, pObj);
         matIndex = __float_as_int(s6.y); // constant material slot of the face, or -1 (Mesh.cpp:242-246: slot 0 = Material{} defaults)
         if (matIndex < 0) {
             const int group = __float_as_int(s6.x);
@@ -788,7 +799,7 @@ PT_DEV void fill_hit(const DScene& sc, const Ray& ray, const Best& best, HitInfo
             if (textured) fill_material_textured(sc, g, tu, tv, h);
             else matIndex = g.material; // normal map only: constant material slot
         }
-        f3 nW = normalize(xform_normal(me.minv, nObj));
+        f3 nW = normalize(identity ? nObj : xform_normal(me.minv, nObj));
         frontFace = (best.tri & kFrontBit) != 0; // Mesh.cpp:230-233, see kFrontBit
         n = frontFace ? nW : -nW;
     }
@@ -832,11 +843,12 @@ PT_DEV bool sample_bsdf(const HitInfo& h, Ray& ray, float& ior, f3& weight, uint
     f3 F0 = mk3(0.04f * om + h.albedo.x * h.metallic, 0.04f * om + h.albedo.y * h.metallic, 0.04f * om + h.albedo.z * h.metallic);
     float roughness = clampf(h.roughness, 0.0f, 1.0f);
     float alpha = fmaxf(1e-4f, roughness * roughness);
-    uint32_t draw = 0;
+    uint32_t ctr = draw_counter(bounce); // draws of this bounce, in order
+    auto next = [&]() { const float u = rand01c(key, ctr); ctr += kDrawStep; return u; };
     const float pT = clampf(h.transmission, 0.0f, 1.0f);
     bool interfaceReflect = false;
     float selPdf = 1.0f;
-    if (pT > 0.0f && rand01(key, bounce, draw++) < pT) { // PathTracer.cpp:99-204
+    if (pT > 0.0f && next() < pT) { // PathTracer.cpp:99-204
         float eta_i = ior;
         float eta_t = h.frontFace ? h.ior : 1.0f;
         float eta = eta_i * frcp(eta_t);
@@ -847,7 +859,7 @@ PT_DEV bool sample_bsdf(const HitInfo& h, Ray& ray, float& ior, f3& weight, uint
         float sin2_t = eta * eta * fmaxf(0.0f, 1.0f - cos_i * cos_i);
         bool TIR = sin2_t > 1.0f;
         float pR = TIR ? 1.0f : F;
-        if (rand01(key, bounce, draw++) < pR) {
+        if (next() < pR) {
             interfaceReflect = true;
             selPdf = fmaxf(1e-3f, pT * pR);
         } else if (!TIR) {
@@ -870,13 +882,13 @@ PT_DEV bool sample_bsdf(const HitInfo& h, Ray& ray, float& ior, f3& weight, uint
         float fv = pow5(1.0f - clampf(cosNo, 0.0f, 1.0f));
         f3 Fv = mk3(F0.x + (1.0f - F0.x) * fv, F0.y + (1.0f - F0.y) * fv, F0.z + (1.0f - F0.z) * fv);
         specProb = clampf((Fv.x + Fv.y + Fv.z) * (1.0f / 3.0f), 0.05f, 0.95f);
-        specular = rand01(key, bounce, draw++) < specProb;
+        specular = next() < specProb;
     }
     // Both lobes draw their direction from the same two counter slots, and both turn a local direction into a
     // world one through the same frame: the uniforms come before the branch and the frame after it, so a wave
     // whose lanes split between the lobes (nearly every wave: 5 % of a diffuse surface's samples are specular)
     // issues them once.
-    const float u1 = rand01(key, bounce, draw), u2 = rand01(key, bounce, draw + 1);
+    const float u1 = rand01c(key, ctr), u2 = rand01c(key, ctr + kDrawStep);
     f3 local; // sampled direction in the (t, b, n) frame
     float k;
     if (specular) { // PathTracer.cpp:124-179 (interface reflection) and 213-283 (specular lobe): same GGX sample

@@ -226,6 +226,9 @@ void fill_mesh_matrices(const HostObject& ho, DMesh& dm)
     M = scale(M, ho.size);
     Mat4 Minv = inverse(M);
     rows3x4(M, dm.m); rows3x4(Minv, dm.minv);
+    bool identity = true;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) identity = identity && dm.m[4 * r + c] == (r == c ? 1.0f : 0.0f) && dm.minv[4 * r + c] == (r == c ? 1.0f : 0.0f);
+    dm.flags = identity ? (dm.flags | 8u) : (dm.flags & ~8u);
 }
 bool group_samples_images(const ptamd_pbr& g)
 {
@@ -669,9 +672,9 @@ int ptamd_scene_commit(ptamd_scene* s)
             }
             const MeshSlots& ms = slots[uploaded[slot].second];
             DMesh dm; std::memset(&dm, 0, sizeof dm);
-            fill_mesh_matrices(ho, dm);
             dm.node_base = ms.node_base; dm.tri_base = ms.tri_base; dm.group_base = ms.group_base; dm.image_base = ms.image_base;
             dm.num_tris = md.num_faces(); dm.root = wide ? 0 : hm.bvh.root; dm.flags = ms.flags;
+            fill_mesh_matrices(ho, dm);
             d.mesh = (int32_t)meshes.size();
             meshes.push_back(dm);
         }
