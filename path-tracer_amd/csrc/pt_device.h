@@ -23,6 +23,11 @@ PT_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 PT_DEV f3 normalize(f3 a) { return a * frsq(dot(a, a)); }
 PT_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 PT_DEV float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+// The minimum instructions as they are: fminf() makes the compiler quieten an operand it cannot prove canonical with an
+// extra v_max x, x, x (the closest-hit distance, on every trip of the node loop); a NaN operand yields the other one
+// either way.
+PT_DEV float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PT_DEV float min3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 // ---------------------------------------------------------------- random source
 // Counter-based replacement for the reference's thread_local mt19937 (PathTracer.cpp:8-16): a PCG
@@ -288,9 +293,9 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
             const float4 z = *reinterpret_cast<const float4*>(az + cur);
             const int2 ch = *reinterpret_cast<const int2*>(nodes + cur + 96);
             float lmin = fmaxf(fmaxf(fmaf(x.x, inv.x, -oi.x), fmaf(y.x, inv.y, -oi.y)), fmaxf(fmaf(z.x, inv.z, -oi.z), 0.0f));
-            float lmax = fminf(fminf(fmaf(x.z, inv.x, -oi.x), fmaf(y.z, inv.y, -oi.y)), fminf(fmaf(z.z, inv.z, -oi.z), closestT));
+            float lmax = min_raw(min3_raw(fmaf(x.z, inv.x, -oi.x), fmaf(y.z, inv.y, -oi.y), fmaf(z.z, inv.z, -oi.z)), closestT);
             float rmin = fmaxf(fmaxf(fmaf(x.y, inv.x, -oi.x), fmaf(y.y, inv.y, -oi.y)), fmaxf(fmaf(z.y, inv.z, -oi.z), 0.0f));
-            float rmax = fminf(fminf(fmaf(x.w, inv.x, -oi.x), fmaf(y.w, inv.y, -oi.y)), fminf(fmaf(z.w, inv.z, -oi.z), closestT));
+            float rmax = min_raw(min3_raw(fmaf(x.w, inv.x, -oi.x), fmaf(y.w, inv.y, -oi.y), fmaf(z.w, inv.z, -oi.z)), closestT);
             bool hl = lmax >= lmin, hr = rmax >= rmin;
             const int left = ch.x, right = ch.y;
             if (hl && hr) {
