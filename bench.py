@@ -38,10 +38,10 @@ import torch.distributed as dist  # noqa: E402
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak: 256 CU x 128 lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 # flops per unit of work (one ray-box slab test 27, one ray-triangle test 47, one sphere test 25, one oriented-box
-# test 60, one shaded hit 250) and bytes per unit on the global-memory traversal (node visit 64, triangle record 48,
+# test 60, one shaded hit 250) and bytes per unit on the global-memory traversal (node visit 64, or 80 for an eight-child node; triangle record 48,
 # closest-hit reconstruction 112 shade + 48 material)
 F_SLAB, F_TRI, F_SPHERE, F_BOX, F_SHADE = 27.0, 47.0, 25.0, 60.0, 250.0
-B_NODE, B_TRI, B_HIT = 64.0, 48.0, 160.0
+B_NODE, B_WIDE_NODE, B_TRI, B_HIT = 64.0, 80.0, 48.0, 160.0
 
 
 def host_cores():
@@ -268,20 +268,25 @@ def main():
         if world == 1:
             n_sph = sum(1 for o in scene["objects"] if o["type"] == "sphere")
             n_box = sum(1 for o in scene["objects"] if o["type"] == "box")
-            flops = (2 * F_SLAB * stats["nodes"] + F_TRI * stats["tris"] + (F_SPHERE * n_sph + F_BOX * n_box) * stats["rays"] + F_SHADE * stats["shade_lanes"])
+            # a visit of a two-child node tests two boxes and reads 64 B; a visit of an eight-child node tests eight
+            # quantised boxes and reads 80 B (meshes of 200 000 faces and more in scenes that do not fit LDS)
+            wide = pt.Info()["wide_nodes"] > 0
+            slabs, node_bytes = (8, B_WIDE_NODE) if wide else (2, B_NODE)
+            flops = (slabs * F_SLAB * stats["nodes"] + F_TRI * stats["tris"] + (F_SPHERE * n_sph + F_BOX * n_box) * stats["rays"] + F_SHADE * stats["shade_lanes"])
             lds_resident = stats["steal_rounds"] == 0  # the work-sharing loop only runs on the global-memory traversal
             launched = float(W) * H * spp_count
             scale = launched / max(1, stats["samples"])
             traffic, traffic_file = measured_traffic(args.config, spp_count, depth)
             if args.config == 3:
-                algo_bytes = (B_NODE * stats["nodes"] + B_TRI * stats["tris"] + B_HIT * stats["shade_lanes"]) * scale + 32.0 * W * H
+                algo_bytes = (node_bytes * stats["nodes"] + B_TRI * stats["tris"] + B_HIT * stats["shade_lanes"]) * scale + 32.0 * W * H
                 achieved = algo_bytes / (kernel_ms * 1e-3) * 1e-9
                 roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                         "bytes_per_ray": algo_bytes / max(1.0, stats["rays"] * scale),
-                        "note": "gather bound: 64 B per node visit, 48 B per triangle test, 160 B per reconstructed hit, as executed "
+                        "note": "gather bound: %d B per node visit, 48 B per triangle test, 160 B per reconstructed hit, as executed "
                                 "by this kernel's own walk (counting launch), plus the film read and written once; most of these "
-                                "requests are served by L2 and the Infinity Cache, so `traffic` (memory side) is far below"}
+                                "requests are served by L2 and the Infinity Cache, so `traffic` (memory side) is below" % node_bytes,
+                        "node_width": slabs}
             else:
                 achieved = flops * scale / (kernel_ms * 1e-3) * 1e-12
                 roof = {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
