@@ -85,7 +85,8 @@ typedef struct ptamd_rect { int32_t x0, y0, x1, y1; } ptamd_rect; /* [x0,x1) x [
  * buffer of its own; ptamd_render_stats reads the one used last). */
 typedef struct ptamd_stats {
     uint64_t samples; /* paths started (top-level TraceRay calls) */
-    uint64_t rays;    /* rays cast, primary + bounces */
+    uint64_t rays;    /* path segments answered, primary + bounces (scenes with meshes read from global memory keep the
+                         camera ray's hit per pixel after the first sample: those segments count, their traversal is not redone) */
     uint64_t nodes;   /* BVH inner-node visits (each tests both child boxes) */
     uint64_t tris;    /* ray-triangle tests */
     /* Wave-level loop trips (64 lanes issue together): lanes-per-trip = rays / ray_trips, nodes / node_trips,

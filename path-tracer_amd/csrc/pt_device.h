@@ -630,9 +630,11 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
 }
 
 // Closest-hit loop of PathTracer::TraceRay (PathTracer.cpp:38-57) over the flat object list. COOP selects the
-// work-sharing traversal (every lane of the wave must then make the call together).
+// work-sharing traversal (every lane of the wave must then make the call together). `helper` (COOP only): this lane
+// needs no answer of its own (its result is discarded by the caller); it enters the meshes without a ray and takes
+// over pending subtrees of the other lanes.
 template <int BLOCK, bool COUNT, bool COOP>
-PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts* counts = nullptr)
+PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts* counts = nullptr, bool helper = false)
 {
     TraversalCounts cnt; cnt.nodes = 0; cnt.tris = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.steal_rounds = 0;
     const float kTMin = 1e-4f, kTMax = 1e30f;
@@ -651,7 +653,7 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
             f3 oo = identity ? ray.o : xform_point(me.minv, ray.o);
             f3 dd = identity ? ray.d : xform_dir(me.minv, ray.d);
             float len2 = dot(dd, dd);
-            const bool valid = len2 != 0.0f;       // Mesh.cpp:64
+            const bool valid = len2 != 0.0f && !(COOP && helper); // Mesh.cpp:64
             if (!COOP && !valid) continue;
             float dirLen = fsqrt(len2);
             float invLen = frcp(dirLen);

@@ -53,6 +53,9 @@ PT_DEV void add_sample(f3& acc, f3 c)
 // that the default kernel carries neither their registers nor their branches.
 constexpr uint32_t kFlagRoulette = 2u; // PTAMD_FLAG_RUSSIAN_ROULETTE
 constexpr int kNumCounters = 10;        // fields of ptamd_stats, in order
+#ifndef PT_PRIMARY_CACHE
+#define PT_PRIMARY_CACHE 1
+#endif
 #ifndef PT_WAVES
 #define PT_WAVES 5
 #endif
@@ -121,16 +124,29 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
     TraversalCounts tc_total; tc_total.nodes = 0; tc_total.tris = 0; tc_total.node_trips = 0; tc_total.tri_trips = 0; tc_total.steal_rounds = 0;
     uint32_t ray_trips = 0, shade_lanes = 0, shade_trips = 0; // wave-level trips of the bounce loop and of its shading block
 
+    // The camera ray of a pixel is the same for every sample (no jitter: Camera.cpp:47-48), and so is its closest hit.
+    // Where idle lanes can take over other lanes' subtrees (COOP) a lane keeps that hit after its first sample and
+    // joins the search as a helper while its path is at bounce 0. (Without work sharing the lane would only wait for
+    // the other 63: measured, no gain.)
+    Best primary; primary.t = 0.f; primary.obj = -1; primary.tri = -1; primary.u = 0.f; primary.v = 0.f;
+    bool havePrimary = false;
+
     while (s < s_end) {
         Best best;
+        const bool cached = COOP && PT_PRIMARY_CACHE && havePrimary && bounce == 0;
         if (COUNT) {
             TraversalCounts tc;
-            best = closest_hit<kBlock, true, COOP>(sc, geom, ray, stack, coop, slot, &tc);
-            ++nrays; tc_total.nodes += tc.nodes; tc_total.tris += tc.tris;
+            best = closest_hit<kBlock, true, COOP>(sc, geom, ray, stack, coop, slot, &tc, cached);
+            ++nrays; // path segments answered, those from the kept camera-ray hit included
+            tc_total.nodes += tc.nodes; tc_total.tris += tc.tris;
             tc_total.node_trips += tc.node_trips; tc_total.tri_trips += tc.tri_trips; tc_total.steal_rounds += tc.steal_rounds;
             if (wave_leader()) ++ray_trips;
         } else {
-            best = closest_hit<kBlock, false, COOP>(sc, geom, ray, stack, coop, slot);
+            best = closest_hit<kBlock, false, COOP>(sc, geom, ray, stack, coop, slot, nullptr, cached);
+        }
+        if (COOP && PT_PRIMARY_CACHE && bounce == 0) {
+            if (cached) best = primary;
+            else { primary = best; havePrimary = true; }
         }
         bool done;
         if (best.obj < 0) {
