@@ -346,6 +346,18 @@ struct Coop { unsigned long long* res; uint32_t* mail; }; // LDS, one entry per 
 #ifndef PT_STEAL_MIN
 #define PT_STEAL_MIN 8   // idle lanes that make a steal round worth its cost
 #endif
+#ifndef PT_WIDE_NODE_BIAS
+#define PT_WIDE_NODE_BIAS 2 // nodes are opened as long as twice the lanes that want one reach the number waiting for a leaf test
+#endif
+#ifndef PT_WIDE_LEAF_BIAS
+#define PT_WIDE_LEAF_BIAS 1 // a leaf trip runs when more than 1/PT_WIDE_LEAF_BIAS as many lanes wait for one as for a node
+#endif
+#ifndef PT_SHARE_LEAVES
+#define PT_SHARE_LEAVES 1
+#endif
+#ifndef PT_SPLIT_GROUPS
+#define PT_SPLIT_GROUPS 1 // the eight-wide walk also hands out parts of current groups
+#endif
 #ifndef PT_STEAL_COOL
 #define PT_STEAL_COOL 0  // node trips to wait after a steal round
 #endif
@@ -532,7 +544,7 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
         const bool wantsNode = !wantsLeaf && (node >= 0 || (gBits >> 8) != 0u || sp > bot);
         const int nNode = __popcll(__ballot(wantsNode)), nLeaf = __popcll(__ballot(wantsLeaf));
         if (nNode + nLeaf == 0) break;
-        if (nNode >= nLeaf) {
+        if (PT_WIDE_NODE_BIAS * nNode >= PT_WIDE_LEAF_BIAS * nLeaf) {
             if (wantsNode) {
                 if (node < 0) {
                     if ((gBits >> 8) == 0u) {
@@ -574,16 +586,38 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
                 gBase = __float_as_uint(h1.x); gBits = (pm & 0xff00u) | imask;
                 pLeaves = pm & 255u; pTriBase = __float_as_uint(h1.y); pMeta0 = __float_as_uint(h1.z); pMeta1 = __float_as_uint(h1.w);
             }
-            // ---- steal round: idle lanes take the oldest pending group of lanes that have one on their stack
+            // ---- steal round: idle lanes take the oldest pending group of lanes that have one on their stack, or the
+            // far part of the current group of a lane whose stack is empty (its upper four slots when both halves hold
+            // hits, else its farthest hit): near the end of a wave's search the pending work sits in a few current groups
             const bool idle = !wantsLeaf && pLeaves == 0u && node < 0 && (gBits >> 8) == 0u && sp == bot;
-            const bool rich = sp > bot;
+            const uint32_t pend = gBits >> 8;
+            const bool rich = sp > bot || (PT_SPLIT_GROUPS && (pend & (pend - 1u)) != 0u) || (PT_SHARE_LEAVES && (pLeaves & (pLeaves - 1u)) != 0u);
             const unsigned long long idleMask = __ballot(idle), richMask = __ballot(rich);
             if (richMask != 0ull && __popcll(idleMask) >= PT_STEAL_MIN) {
                 if (COUNT) { if (wave_leader()) ++cnt.steal_rounds; }
                 const int pairs = min(__popcll(idleMask), __popcll(richMask));
                 const int r = rank_in(idle ? idleMask : richMask);
                 const bool victim = rich && r < pairs, thief = idle && r < pairs;
-                if (victim) coop.mail[waveBase + r] = (uint32_t)lane;
+                uint32_t oBase = gBase, oBits = 0u; // what a victim hands over
+                if (victim) {
+                    coop.mail[waveBase + r] = (uint32_t)lane;
+                    if (sp > bot) {
+                        oBase = stack[(2 * bot) * BLOCK + slot]; oBits = stack[(2 * bot + 1) * BLOCK + slot];
+                        ++bot;
+                    } else if ((pend & (pend - 1u)) != 0u) {
+                        const uint32_t up = pend & 0xf0u;
+                        const uint32_t give = (up != 0u && (pend & 0x0fu) != 0u) ? up : (0x80000000u >> __clz((int)pend));
+                        oBits = (give << 8) | (gBits & 255u);
+                        gBits &= ~(give << 8);
+                    } else { // the farthest of several hit leaf children, as (first triangle slot, primitive count and quad mask)
+                        const uint32_t i = 31u - (uint32_t)__clz((int)pLeaves);
+                        pLeaves &= ~(1u << i);
+                        const uint32_t sl = i ^ oct;
+                        const uint32_t m = ((sl & 4u ? pMeta1 : pMeta0) >> (8u * (sl & 3u))) & 255u;
+                        oBase = pTriBase + (m & 31u);
+                        oBits = 0x80000000u | (m >> 5);
+                    }
+                }
                 __builtin_amdgcn_wave_barrier(); // LDS executes a wave's operations in order; this keeps the compiler from reordering them
                 int src = lane;
                 if (thief) src = (int)coop.mail[waveBase + r];
@@ -591,13 +625,15 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
                 o.x = __shfl(o.x, src, 64); o.y = __shfl(o.y, src, 64); o.z = __shfl(o.z, src, 64);
                 d.x = __shfl(d.x, src, 64); d.y = __shfl(d.y, src, 64); d.z = __shfl(d.z, src, 64);
                 tMinObj = __shfl(tMinObj, src, 64); bound = __shfl(bound, src, 64); owner = __shfl(owner, src, 64);
-                const int sBot = __shfl(bot, src, 64);
+                oBase = __shfl(oBase, src, 64); oBits = __shfl(oBits, src, 64);
                 if (thief) {
                     inv = inverse(d); oct = octant(inv);
-                    gBase = stack[(2 * sBot) * BLOCK + waveBase + src]; gBits = stack[(2 * sBot + 1) * BLOCK + waveBase + src];
                     sp = 0; bot = 0;
+                    if (oBits & 0x80000000u) { // one leaf: every meta byte describes it, so any slot number finds it
+                        gBase = 0u; gBits = 0u;
+                        pTriBase = oBase; pMeta0 = pMeta1 = ((oBits & 7u) << 5) * 0x01010101u; pLeaves = 1u;
+                    } else { gBase = oBase; gBits = oBits; }
                 }
-                if (victim) ++bot;
             }
         } else if (wantsLeaf) {
             const uint32_t i = (uint32_t)__ffs((int)pLeaves) - 1u;
