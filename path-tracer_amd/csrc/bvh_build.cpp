@@ -376,12 +376,82 @@ void children_of(const DNode& n, WideItem& l, WideItem& r)
     r.lo[0] = n.rmin01[0]; r.lo[1] = n.rmin01[1]; r.lo[2] = n.rmin2; r.hi[0] = n.rmax[0]; r.hi[1] = n.rmax[1]; r.hi[2] = n.rmax[2];
 }
 
+// Which binary nodes become eight-wide nodes, chosen to minimise the summed surface area of the wide nodes (the
+// expected number of node visits of a random ray), by dynamic programming over the binary tree (after Ylitie, Karras
+// and Laine, "Efficient incoherent ray traversal on GPUs through compressed wide BVHs", 2017, section 3.2, with the
+// leaves of the binary tree kept as they are):
+//   cost[n][i], i = 1..7: least cost of turning the subtree of inner node n into at most i children of one wide node;
+//   i = 1 makes n a wide node of its own: area(n) + (its two subtrees shared out over 8 slots);
+//   i > 1: either the two subtrees share out i slots (split[n][i] of them to the left one) or fewer slots do as well.
+// A leaf takes one slot and costs nothing here (its tests cost the same wherever it hangs).
+struct WidePlan {
+    std::vector<float> cost;    // [node][8], index 1..7 used
+    std::vector<uint8_t> split; // [node][9], index 2..8: slots given to the left child when the children share i slots
+    float c(int32_t ref, int i) const { return ref < 0 ? 0.f : cost[(size_t)ref * 8 + (size_t)i]; }
+};
+
+WidePlan plan_wide(const BvhResult& res)
+{
+    const size_t n = res.nodes.size();
+    WidePlan pl; pl.cost.assign(n * 8, 0.f); pl.split.assign(n * 9, 1);
+    // children before parents: an explicit post-order walk (the node array's order is the builder's business)
+    std::vector<int32_t> order; order.reserve(n);
+    {
+        std::vector<int32_t> stack; stack.push_back(res.root);
+        while (!stack.empty()) {
+            const int32_t v = stack.back(); stack.pop_back();
+            order.push_back(v);
+            const DNode& nd = res.nodes[(size_t)v];
+            if (nd.left >= 0) stack.push_back(nd.left);
+            if (nd.right >= 0) stack.push_back(nd.right);
+        }
+    }
+    for (size_t oi = order.size(); oi-- > 0;) {
+        const int32_t v = order[oi];
+        WideItem l, r; children_of(res.nodes[(size_t)v], l, r);
+        WideItem self; self.ref = v;
+        for (int k = 0; k < 3; ++k) { self.lo[k] = std::min(l.lo[k], r.lo[k]); self.hi[k] = std::max(l.hi[k], r.hi[k]); }
+        float shared[9]; // least cost of the two subtrees sharing j slots
+        for (int j = 2; j <= 8; ++j) {
+            float best = std::numeric_limits<float>::max(); int bk = 1;
+            for (int k = 1; k < j; ++k) {
+                const float cst = pl.c(l.ref, std::min(k, 7)) + pl.c(r.ref, std::min(j - k, 7));
+                if (cst < best) { best = cst; bk = k; }
+            }
+            shared[j] = best; pl.split[(size_t)v * 9 + (size_t)j] = (uint8_t)bk;
+        }
+        float* c = &pl.cost[(size_t)v * 8];
+        const float area = std::max(item_area(self), 0.f);
+        c[1] = area + shared[8];
+        for (int i = 2; i <= 7; ++i) c[i] = std::min(shared[i], c[i - 1]);
+    }
+    return pl;
+}
+
+// The children (leaves and inner nodes that become wide nodes themselves) that `it` contributes to its wide parent when
+// it may take up to `slots` of the parent's slots.
+void gather_children(const BvhResult& res, const WidePlan& pl, const WideItem& it, int slots, WideItem* out, int& n)
+{
+    if (it.ref < 0 || slots <= 1) { out[n++] = it; return; }
+    const float* c = &pl.cost[(size_t)it.ref * 8];
+    int i = std::min(slots, 7);
+    while (i > 1 && c[i] == c[i - 1]) --i; // fewer slots do as well
+    if (i == 1) { out[n++] = it; return; }
+    WideItem l, r; children_of(res.nodes[(size_t)it.ref], l, r);
+    const int k = pl.split[(size_t)it.ref * 9 + (size_t)i];
+    gather_children(res, pl, l, k, out, n);
+    gather_children(res, pl, r, i - k, out, n);
+}
+
 } // namespace
 
 void build_wide(BvhResult& res)
 {
     res.wide.clear(); res.wide_order.clear(); res.wide_depth = 0;
     if (res.root < 0 || res.nodes.empty()) return;
+    const bool greedy = std::getenv("PTAMD_WIDE_GREEDY") != nullptr; // the older collapse: open the largest child until eight
+    WidePlan plan;
+    if (!greedy) plan = plan_wide(res);
     struct Pending { int32_t binary; uint32_t wide; int level; };
     std::vector<Pending> queue;
     res.wide.emplace_back();
@@ -394,7 +464,14 @@ void build_wide(BvhResult& res)
         // surface area until there are eight children or only leaves.
         WideItem items[8]; int n = 2;
         children_of(res.nodes[(size_t)pe.binary], items[0], items[1]);
-        while (n < 8) {
+        if (!greedy) {
+            const WideItem l = items[0], r = items[1];
+            const int k = plan.split[(size_t)pe.binary * 9 + 8];
+            n = 0;
+            gather_children(res, plan, l, k, items, n);
+            gather_children(res, plan, r, 8 - k, items, n);
+        }
+        while (greedy && n < 8) {
             int best = -1; float bestArea = -1.f;
             for (int i = 0; i < n; ++i) if (items[i].ref >= 0 && item_area(items[i]) > bestArea) { bestArea = item_area(items[i]); best = i; }
             if (best < 0) break;

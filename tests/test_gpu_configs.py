@@ -351,6 +351,16 @@ def test_wide_nodes_agree_with_binary_nodes(gpu, monkeypatch):
         close = np.abs(fb - fw).max(axis=-1) <= 1e-4 + 1e-4 * np.abs(fb).max(axis=-1)
         assert close.mean() >= 0.99, close.mean()
         assert sb["samples"] == sw["samples"] and sw["steal_rounds"] > 0
+        # the planned collapse (least summed node area) against the older greedy one: never more nodes, the same hits
+        planned = pt.Info()["wide_nodes"]
+        monkeypatch.setenv("PTAMD_WIDE_GREEDY", "1")
+        pg, _ = gpu.build_scene(scene)
+        monkeypatch.delenv("PTAMD_WIDE_GREEDY")
+        assert planned <= pg.Info()["wide_nodes"]
+        hg, _ = pg.TraversalCounts(np.concatenate([rays, extra]))
+        assert (hg[:, 0] == hw[:, 0]).mean() >= 0.9995
+        both = (hg[:, 0] == 1) & (hw[:, 0] == 1)
+        assert (np.abs(hg[both, 1] - hw[both, 1]) <= 1e-6 * np.abs(hw[both, 1])).mean() >= 0.999
 
 
 def test_quads_far_from_the_origin(gpu, monkeypatch):

@@ -38,6 +38,12 @@ KERNEL(k_mul24, "v_mul_u32_u24 %0, %0, %1")
 KERNEL(k_mullo, "v_mul_lo_u32 %0, %0, %1")
 KERNEL(k_lshladd, "v_lshl_add_u32 %0, %0, 2, %1")
 KERNEL(k_mov, "v_mov_b32 %0, %1")
+KERNEL(k_mix_lo, "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]")
+KERNEL(k_mix_hi, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]")
+KERNEL(k_cvt_ub1, "v_cvt_f32_ubyte1 %0, %0")
+KERNEL(k_cvt_f16, "v_cvt_f32_f16 %0, %0")
+KERNEL(k_bfe, "v_bfe_u32 %0, %0, 8, 8")
+KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %2")
 
 template <class K> static void run(const char* name, K kernel, float* out)
 {
@@ -58,6 +64,6 @@ int main()
     float* out; CHECK(hipMalloc(&out, 256 * 8 * 256 * 4));
 #define RUN(k) run(#k, k, out)
     RUN(k_fma); RUN(k_mul); RUN(k_add); RUN(k_max); RUN(k_min); RUN(k_max3); RUN(k_min3); RUN(k_med3); RUN(k_imax); RUN(k_imax3); RUN(k_umin);
-    RUN(k_iadd); RUN(k_and); RUN(k_cndmask); RUN(k_cmp); RUN(k_rcp); RUN(k_mul24); RUN(k_mullo); RUN(k_lshladd); RUN(k_mov);
+    RUN(k_iadd); RUN(k_and); RUN(k_cndmask); RUN(k_cmp); RUN(k_rcp); RUN(k_mul24); RUN(k_mullo); RUN(k_lshladd); RUN(k_mov); RUN(k_mix_lo); RUN(k_mix_hi); RUN(k_cvt_ub1); RUN(k_cvt_f16); RUN(k_bfe); RUN(k_perm);
     return 0;
 }
