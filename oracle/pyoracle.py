@@ -198,6 +198,17 @@ class Scene:
                 out[y, x] = buf[:]
         return out
 
+    def rays_at(self, ys, xs):
+        """Camera rays of the pixels (y, x) for y in ys, x in xs: [len(ys), len(xs), 6]."""
+        w, h = self.w, self.h_px
+        out = np.zeros((len(ys), len(xs), 6), np.float32)
+        buf = (C.c_float * 6)()
+        for i, y in enumerate(ys):
+            for j, x in enumerate(xs):
+                lib().po_camera_ray(C.byref(self.cam), int(x), int(y), w, h, buf)
+                out[i, j] = buf[:]
+        return out
+
     def closest_hits(self, rays):
         r = np.ascontiguousarray(rays.reshape(-1, 6), np.float32)
         out = np.zeros((r.shape[0], 20), np.float32)

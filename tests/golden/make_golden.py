@@ -189,10 +189,32 @@ def golden_scenes():
     }
 
 
+def camera_4k():
+    """Camera::GetRay known answers at 3840x2160 for three cameras (the default one, the raised and turned one of the dragon
+    scene, a rolled wide-angle one): the reference's rays on a lattice of rows and columns that includes the frame's edges."""
+    ys = np.r_[0:2160:83, 2159].astype(np.int32)
+    xs = np.r_[0:3840:97, 3839].astype(np.int32)
+    cams = [presets.default_camera(),
+            dict(presets.default_camera(), pos=(2.78, 2.4, -1.8), rot=(17.0, 180.0, 0.0), fov=52.0),
+            dict(presets.default_camera(), pos=(-3.5, 7.25, 11.0), rot=(-31.0, 23.0, 14.0), fov=97.0)]
+    out = {"ys": ys, "xs": xs}
+    for i, cam in enumerate(cams):
+        scene = {"film": (3840, 2160), "camera": cam, "objects": presets.sphere_cornell(8, 8)["objects"]}
+        rays = po.ref_rays(scene).reshape(2160, 3840, 6)
+        out["rays%d" % i] = np.ascontiguousarray(rays[ys][:, xs])
+        out["cam%d" % i] = np.array(list(cam["pos"]) + list(cam["rot"]) + [cam["fov"], cam["near"], cam["far"]], np.float32)
+    np.savez_compressed(os.path.join(HERE, "camera_4k.npz"), **out)
+    print("camera_4k", {k: v.shape for k, v in out.items()})
+
+
 def main():
     assert po.have_ref(), "build oracle/_ref first: make -C oracle ref"
     os.chdir(ROOT)  # mesh paths in the scenes are relative to the repo root
     only = sys.argv[1:]
+    if not only or "camera_4k" in only:
+        camera_4k()
+        if only == ["camera_4k"]:
+            return
     import tempfile
     field = os.path.join(tempfile.mkdtemp(prefix="ptgold_"), "dragon_field.glb")
     dragon.write_dragon_field(field)

@@ -311,6 +311,19 @@ def test_tiny_meshes(gpu, faces, monkeypatch):
         assert close.mean() >= 0.95, close.mean()
 
 
+def test_camera_rays_at_4k(gpu, golden):
+    """Camera::GetRay at 3840x2160 against the reference's rays (tests/golden/camera_4k.npz: three cameras, a lattice of
+    rows and columns with the frame's edges): 2e-6, as at the small sizes."""
+    from test_oracle_golden import cameras_4k
+    g = golden("camera_4k")
+    for scene, want in cameras_4k(g):
+        scene = dict(scene, objects=presets.sphere_cornell(8, 8)["objects"])
+        _, cam = gpu.build_scene(scene)
+        rays = cam.GetRays().reshape(2160, 3840, 6)[g["ys"]][:, g["xs"]]
+        assert np.abs(rays - want).max() <= 2e-6
+        assert np.abs(np.linalg.norm(rays[..., 3:], axis=-1) - 1.0).max() <= 1e-6
+
+
 def test_wide_nodes_agree_with_binary_nodes(gpu, monkeypatch):
     """Large meshes are walked through eight-wide nodes with 8-bit child boxes, smaller ones through binary nodes. With
     the size threshold taken away (PTAMD_WIDE_MIN_FACES) the wide walk must find the same closest hits and give the same

@@ -24,6 +24,23 @@ def test_camera_rays_bit_exact(name, oracle_scenes, golden):
     assert np.array_equal(r.view(np.uint32), g["rays"].view(np.uint32))
 
 
+def cameras_4k(g):
+    """(scene dict, expected rays on the lattice) for the cameras of tests/golden/camera_4k.npz."""
+    for i in range(3):
+        c = g["cam%d" % i]
+        cam = {"pos": tuple(map(float, c[0:3])), "rot": tuple(map(float, c[3:6])), "fov": float(c[6]), "near": float(c[7]), "far": float(c[8])}
+        yield {"film": (3840, 2160), "camera": cam, "objects": []}, g["rays%d" % i]
+
+
+def test_camera_rays_at_4k_bit_exact(golden):
+    """Camera::GetRay at 3840x2160 for three cameras (default, raised and turned, rolled wide-angle), on a lattice of
+    rows and columns that includes the frame's edges: bit for bit the reference's rays."""
+    g = golden("camera_4k")
+    for scene, want in cameras_4k(g):
+        r = po.Scene(scene).rays_at(g["ys"], g["xs"])
+        assert np.array_equal(r.view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_closest_hit_records_bit_exact(name, oracle_scenes, golden):
     """Sphere/Box/Mesh::RayIntersect + the closest-hit loop: t, p, n, frontFace and material, bit for bit."""
