@@ -311,6 +311,48 @@ def test_tiny_meshes(gpu, faces, monkeypatch):
         assert close.mean() >= 0.95, close.mean()
 
 
+def test_config3_full_combination(gpu, golden, dragon_field_glb):
+    """Config 3 as benchmarked: the 1 M-triangle dragon field in the closed room at 1920x1080, without and with the cubemap
+    sky. Exact sample counts; sample ranges add up bit for bit (the kept camera-ray hit of the one-launch render included);
+    the frame agrees with the reference's 96x54 golden render of the same view (mean luminance, and pixel by pixel after
+    averaging 20x20 blocks, no further from the mean of the reference's two 256-spp runs than those are from each other)."""
+    from scenes import dragon
+    w, h = 1920, 1080
+    scene = dragon.config3_scene(dragon_field_glb, w, h)
+    pt, cam = gpu.build_scene(scene)
+    assert pt.Info()["triangles"] == 1_000_000 and pt.Info()["wide_nodes"] > 0
+    g = golden("dragon_field")
+    spp = 48
+    film = gpu.Film(w, h)
+    gpu.Render(cam, pt, film, spp, 8, count=True)
+    st = gpu.RenderStats()
+    assert st["samples"] == w * h * spp and st["steal_rounds"] > 0
+    assert np.array_equal(film.Samples(), np.full((h, w), spp, np.uint32))
+    f2 = gpu.Film(w, h)
+    gpu.Render(cam, pt, f2, 1, 8, spp_begin=0)
+    gpu.Render(cam, pt, f2, 20, 8, spp_begin=1)
+    gpu.Render(cam, pt, f2, spp - 21, 8, spp_begin=21)
+    assert np.array_equal(f2.Accum()[::5].view(np.uint32), film.Accum()[::5].view(np.uint32))
+    A = film.Average()
+    assert np.isfinite(A).all()
+    ref = 0.5 * (g["avg_a"].astype(np.float32) + g["avg_b"].astype(np.float32))
+    ref_lum = 0.5 * (float(g["mean_lum_a"]) + float(g["mean_lum_b"]))
+    assert abs(lum(A).mean() - ref_lum) <= 0.03 * ref_lum
+    blocks = A.reshape(54, 20, 96, 20, 3).mean(axis=(1, 3))
+    err = np.abs(blocks - ref).max(axis=-1)
+    own = np.abs(g["avg_a"].astype(np.float32) - g["avg_b"].astype(np.float32)).max(axis=-1)  # the reference against itself
+    assert np.median(err) <= np.median(own) and (err <= 0.15).mean() >= (own <= 0.15).mean(), (np.median(err), (err <= 0.15).mean())
+    # with the sky behind the open front: paths that leave the room pick up the cubemap instead of the constant
+    m = 16
+    sky = np.full((6, m, m, 4), 255, np.uint8); sky[..., 0] = 60; sky[..., 1] = 120
+    pt.SetSkybox(sky, 1.5)
+    fs = gpu.Film(w, h)
+    gpu.Render(cam, pt, fs, 8, 8)
+    S = fs.Average()
+    assert np.isfinite(S).all() and np.array_equal(fs.Samples(), np.full((h, w), 8, np.uint32))
+    assert S[..., 2].mean() > 1.05 * A[..., 2].mean()  # a bluer, brighter exit than the 0.2 grey
+
+
 def test_camera_rays_at_4k(gpu, golden):
     """Camera::GetRay at 3840x2160 against the reference's rays (tests/golden/camera_4k.npz: three cameras, a lattice of
     rows and columns with the frame's edges): 2e-6, as at the small sizes."""
