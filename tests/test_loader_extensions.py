@@ -213,3 +213,48 @@ def test_jpeg_images_decode_to_the_reference_texels(tmp_path):
             ptamd.load_model(path)
         except ptamd.PtamdError as e:
             assert "JPEG" in str(e) or "image" in str(e)
+
+
+def test_mutated_model_files_never_crash_the_loader(tmp_path):
+    """Byte-level mutations of the committed .glb files (flipped bytes anywhere: header, JSON, accessors' data, PNG and
+    JPEG streams; truncations): every load either succeeds or raises a clean error. Runs in a child process, so a crash
+    of the native loader fails this test instead of ending the session."""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, "path-tracer_amd"); sys.path.insert(0, ".")
+import ptamd
+tmp = sys.argv[1]
+rng = np.random.default_rng(2024)
+ok = bad = 0
+for name in ("cornell_mesh", "textured", "textured_jpeg", "blob"):
+    raw = np.frombuffer(open("tests/golden/%s.glb" % name, "rb").read(), np.uint8)
+    for trial in range(120):
+        m = raw.copy()
+        kind = trial % 4
+        if kind == 0:    # a few flipped bytes anywhere
+            idx = rng.integers(0, len(m), int(rng.integers(1, 9)))
+            m[idx] = rng.integers(0, 256, len(idx))
+        elif kind == 1:  # flipped bytes in the JSON chunk
+            n = int(np.frombuffer(m[12:16].tobytes(), "<u4")[0])
+            idx = 20 + rng.integers(0, n, int(rng.integers(1, 5)))
+            m[idx] = rng.integers(32, 127, len(idx))
+        elif kind == 2:  # truncated
+            m = m[:int(rng.integers(1, len(m)))]
+        else:            # a run of bytes overwritten
+            a = int(rng.integers(0, len(m) - 64)); m[a:a + int(rng.integers(4, 64))] = int(rng.integers(0, 256))
+        path = os.path.join(tmp, "m.glb")
+        m.tofile(path)
+        try:
+            ptamd.load_model(path); ok += 1
+        except ptamd.PtamdError:
+            bad += 1
+print("loaded", ok, "refused", bad)
+assert ok > 0 and bad > 0
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", script, str(tmp_path)], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
