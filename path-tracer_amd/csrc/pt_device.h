@@ -352,6 +352,9 @@ struct Coop { unsigned long long* res; uint32_t* mail; }; // LDS, one entry per 
 #ifndef PT_WIDE_LEAF_BIAS
 #define PT_WIDE_LEAF_BIAS 1 // a leaf trip runs when more than 1/PT_WIDE_LEAF_BIAS as many lanes wait for one as for a node
 #endif
+#ifndef PT_STEAL_AFTER_LEAVES
+#define PT_STEAL_AFTER_LEAVES 1
+#endif
 #ifndef PT_SHARE_LEAVES
 #define PT_SHARE_LEAVES 1
 #endif
@@ -544,7 +547,8 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
         const bool wantsNode = !wantsLeaf && (node >= 0 || (gBits >> 8) != 0u || sp > bot);
         const int nNode = __popcll(__ballot(wantsNode)), nLeaf = __popcll(__ballot(wantsLeaf));
         if (nNode + nLeaf == 0) break;
-        if (PT_WIDE_NODE_BIAS * nNode >= PT_WIDE_LEAF_BIAS * nLeaf) {
+        const bool nodeTrip = PT_WIDE_NODE_BIAS * nNode >= PT_WIDE_LEAF_BIAS * nLeaf;
+        if (nodeTrip) {
             if (wantsNode) {
                 if (node < 0) {
                     if ((gBits >> 8) == 0u) {
@@ -586,10 +590,34 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
                 gBase = __float_as_uint(h1.x); gBits = (pm & 0xff00u) | imask;
                 pLeaves = pm & 255u; pTriBase = __float_as_uint(h1.y); pMeta0 = __float_as_uint(h1.z); pMeta1 = __float_as_uint(h1.w);
             }
+        } else if (wantsLeaf) {
+            const uint32_t i = (uint32_t)__ffs((int)pLeaves) - 1u;
+            pLeaves &= pLeaves - 1u;
+            const uint32_t s = i ^ oct;
+            const uint32_t m = ((s & 4u ? pMeta1 : pMeta0) >> (8u * (s & 3u))) & 255u;
+            uint32_t slotIdx = pTriBase + (m & 31u), mask = m >> 6;
+            const uint32_t prims = ((m >> 5) & 1u) + 1u;
+            for (uint32_t k = 0; k < prims; ++k, mask >>= 1) {
+                if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
+                const bool quad = (mask & 1u) != 0u;
+                const uint32_t rec = slotIdx;
+                slotIdx += quad ? 2u : 1u;
+                float t, u, v, dn;
+                if (!tri_test<true>(tris + (size_t)rec * 3, o, d, tMinObj, bound, quad, t, u, v, dn)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
+                int tri = (int)rec + ((quad && u + v > 1.0f) ? 1 : 0);
+                if (me.flags & 1u) { // Mesh.cpp:106-125
+                    tri = hit_triangle(tris, (int)rec, quad, o, d, u, v, dn);
+                    if (!alpha_pass(sc, me, tri, u, v)) continue;
+                }
+                bound = t;
+                atomicMin(&coop.res[waveBase + owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((uint32_t)tri + 1u));
+            }
+        }
+        if (PT_STEAL_AFTER_LEAVES || nodeTrip) {
             // ---- steal round: idle lanes take the oldest pending group of lanes that have one on their stack, or the
             // far part of the current group of a lane whose stack is empty (its upper four slots when both halves hold
             // hits, else its farthest hit): near the end of a wave's search the pending work sits in a few current groups
-            const bool idle = !wantsLeaf && pLeaves == 0u && node < 0 && (gBits >> 8) == 0u && sp == bot;
+            const bool idle = pLeaves == 0u && node < 0 && (gBits >> 8) == 0u && sp == bot;
             const uint32_t pend = gBits >> 8;
             const bool rich = sp > bot || (PT_SPLIT_GROUPS && (pend & (pend - 1u)) != 0u) || (PT_SHARE_LEAVES && (pLeaves & (pLeaves - 1u)) != 0u);
             const unsigned long long idleMask = __ballot(idle), richMask = __ballot(rich);
@@ -634,28 +662,6 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
                         pTriBase = oBase; pMeta0 = pMeta1 = ((oBits & 7u) << 5) * 0x01010101u; pLeaves = 1u;
                     } else { gBase = oBase; gBits = oBits; }
                 }
-            }
-        } else if (wantsLeaf) {
-            const uint32_t i = (uint32_t)__ffs((int)pLeaves) - 1u;
-            pLeaves &= pLeaves - 1u;
-            const uint32_t s = i ^ oct;
-            const uint32_t m = ((s & 4u ? pMeta1 : pMeta0) >> (8u * (s & 3u))) & 255u;
-            uint32_t slotIdx = pTriBase + (m & 31u), mask = m >> 6;
-            const uint32_t prims = ((m >> 5) & 1u) + 1u;
-            for (uint32_t k = 0; k < prims; ++k, mask >>= 1) {
-                if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
-                const bool quad = (mask & 1u) != 0u;
-                const uint32_t rec = slotIdx;
-                slotIdx += quad ? 2u : 1u;
-                float t, u, v, dn;
-                if (!tri_test<true>(tris + (size_t)rec * 3, o, d, tMinObj, bound, quad, t, u, v, dn)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
-                int tri = (int)rec + ((quad && u + v > 1.0f) ? 1 : 0);
-                if (me.flags & 1u) { // Mesh.cpp:106-125
-                    tri = hit_triangle(tris, (int)rec, quad, o, d, u, v, dn);
-                    if (!alpha_pass(sc, me, tri, u, v)) continue;
-                }
-                bound = t;
-                atomicMin(&coop.res[waveBase + owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((uint32_t)tri + 1u));
             }
         }
     }
