@@ -184,9 +184,8 @@ PT_DEV f3 xform_normal(const float* minv, f3 n)
 PT_DEV float plane_coord(float4 q, f3 h) { return fmaf(q.x, h.x, fmaf(q.y, h.y, fmaf(q.z, h.z, q.w))); }      // q.xyz . h + q.w
 PT_DEV float plane_offset(float4 q, f3 o) { return fmaf(-q.x, o.x, fmaf(-q.y, o.y, fmaf(-q.z, o.z, q.w))); } // q.w - q.xyz . o
 template <bool INCLUSIVE>
-PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float tHi, bool quad, float& t, float& u, float& v, float& dn)
+PT_DEV bool tri_test_record(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tLo, float tHi, bool quad, float& t, float& u, float& v, float& dn)
 {
-    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     const f3 n = mk3(q0.x, q0.y, q0.z);
     dn = dot(n, d);
     t = plane_offset(q0, o) * frcp(dn);
@@ -196,6 +195,11 @@ PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float
     // a quad (two triangles forming a parallelogram, this record = the one at corner a) covers the whole unit square
     return !(fabsf(dn) < 1e-8f) & (t > 1e-8f) & !(t < tLo) & !(INCLUSIVE ? t > tHi : t >= tHi) & !(u < 0.0f) & !(u > 1.0f) & !(v < 0.0f)
            & !(quad ? v > 1.0f : u + v > 1.0f);
+}
+template <bool INCLUSIVE>
+PT_DEV bool tri_test(const float4* __restrict__ tp, f3 o, f3 d, float tLo, float tHi, bool quad, float& t, float& u, float& v, float& dn)
+{
+    return tri_test_record<INCLUSIVE>(tp[0], tp[1], tp[2], o, d, tLo, tHi, quad, t, u, v, dn);
 }
 
 PT_DEV float4 sample_nearest(const DScene& sc, int img, float u, float v);
@@ -595,22 +599,33 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
             pLeaves &= pLeaves - 1u;
             const uint32_t s = i ^ oct;
             const uint32_t m = ((s & 4u ? pMeta1 : pMeta0) >> (8u * (s & 3u))) & 255u;
-            uint32_t slotIdx = pTriBase + (m & 31u), mask = m >> 6;
-            const uint32_t prims = ((m >> 5) & 1u) + 1u;
-            for (uint32_t k = 0; k < prims; ++k, mask >>= 1) {
-                if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
-                const bool quad = (mask & 1u) != 0u;
-                const uint32_t rec = slotIdx;
-                slotIdx += quad ? 2u : 1u;
-                float t, u, v, dn;
-                if (!tri_test<true>(tris + (size_t)rec * 3, o, d, tMinObj, bound, quad, t, u, v, dn)) continue; // Mesh.cpp:104; an equal distance is settled by the published minimum
+            // both records of a two-primitive leaf are requested before the first test: their latencies overlap
+            const uint32_t rec0 = pTriBase + (m & 31u), mask = m >> 6;
+            const bool two = ((m >> 5) & 1u) != 0u;
+            const uint32_t rec1 = two ? rec0 + ((mask & 1u) ? 2u : 1u) : rec0;
+            const float4* __restrict__ p0 = tris + (size_t)rec0 * 3;
+            const float4* __restrict__ p1 = tris + (size_t)rec1 * 3;
+            const float4 a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+            auto accept = [&](uint32_t rec, bool quad, float t, float u, float v, float dn) {
                 int tri = (int)rec + ((quad && u + v > 1.0f) ? 1 : 0);
                 if (me.flags & 1u) { // Mesh.cpp:106-125
                     tri = hit_triangle(tris, (int)rec, quad, o, d, u, v, dn);
-                    if (!alpha_pass(sc, me, tri, u, v)) continue;
+                    if (!alpha_pass(sc, me, tri, u, v)) return;
                 }
                 bound = t;
                 atomicMin(&coop.res[waveBase + owner], ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)((uint32_t)tri + 1u));
+            };
+            {
+                if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
+                float t, u, v, dn;
+                const bool quad = (mask & 1u) != 0u;
+                if (tri_test_record<true>(a0, a1, a2, o, d, tMinObj, bound, quad, t, u, v, dn)) accept(rec0, quad, t, u, v, dn); // Mesh.cpp:104; an equal distance is settled by the published minimum
+            }
+            if (two) {
+                if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
+                float t, u, v, dn;
+                const bool quad = (mask & 2u) != 0u;
+                if (tri_test_record<true>(b0, b1, b2, o, d, tMinObj, bound, quad, t, u, v, dn)) accept(rec1, quad, t, u, v, dn);
             }
         }
         if (PT_STEAL_AFTER_LEAVES || nodeTrip) {

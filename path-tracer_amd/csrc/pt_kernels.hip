@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
     const uint32_t stackBytes = (uint32_t)rp.stack_depth * kBlock * (uint32_t)sizeof(StackEntry);
     float* lds_acc = reinterpret_cast<float*>(lds_raw + stackBytes); // [kLaneFloats][kBlock]
     // Either the staged geometry (small scenes, lean traversal) or the work-sharing words of the cooperative
-    // traversal (8 + 4 bytes per lane, and 8 for the kept camera-ray hit; meshes read from global memory) follow the per-lane floats.
+    // traversal (8 + 4 bytes per lane, and 20 for the kept camera-ray hit; meshes read from global memory) follow the per-lane floats.
     constexpr bool COOP = !LDS_GEOM;
     Coop coop;
     coop.res = reinterpret_cast<unsigned long long*>(lds_raw + stackBytes + 4 * kLaneFloats * kBlock);
@@ -128,9 +128,8 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
     // Where idle lanes can take over other lanes' subtrees (COOP) a lane keeps that hit after its first sample and
     // joins the search as a helper while its path is at bounce 0. (Without work sharing the lane would only wait for
     // the other 63: measured, no gain.)
-    // (its barycentrics wait in LDS: two registers fewer through the bounce loop)
-    float primaryT = 0.f; int primaryObj = -1, primaryTri = -1;
-    float* primaryUV = reinterpret_cast<float*>(lds_raw + stackBytes + (4 * kLaneFloats + 12) * kBlock); // [2][kBlock], COOP only
+    // (it waits in LDS: five registers fewer through the bounce loop)
+    float* primary = reinterpret_cast<float*>(lds_raw + stackBytes + (4 * kLaneFloats + 12) * kBlock); // [5][kBlock], COOP only
     bool havePrimary = false;
 
     while (s < s_end) {
@@ -147,8 +146,14 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
             best = closest_hit<kBlock, false, COOP>(sc, geom, ray, stack, coop, slot, nullptr, cached);
         }
         if (COOP && PT_PRIMARY_CACHE && bounce == 0) {
-            if (cached) { best.t = primaryT; best.obj = primaryObj; best.tri = primaryTri; best.u = primaryUV[slot]; best.v = primaryUV[kBlock + slot]; }
-            else { primaryT = best.t; primaryObj = best.obj; primaryTri = best.tri; primaryUV[slot] = best.u; primaryUV[kBlock + slot] = best.v; havePrimary = true; }
+            if (cached) {
+                best.t = primary[slot]; best.obj = __float_as_int(primary[kBlock + slot]); best.tri = __float_as_int(primary[2 * kBlock + slot]);
+                best.u = primary[3 * kBlock + slot]; best.v = primary[4 * kBlock + slot];
+            } else {
+                primary[slot] = best.t; primary[kBlock + slot] = __int_as_float(best.obj); primary[2 * kBlock + slot] = __int_as_float(best.tri);
+                primary[3 * kBlock + slot] = best.u; primary[4 * kBlock + slot] = best.v;
+                havePrimary = true;
+            }
         }
         bool done;
         if (best.obj < 0) {
@@ -297,7 +302,7 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const size_t geomBytes = fits ? (size_t)(sc.lds_node_f4 + sc.num_tris * 3u) * 16 : 0;
     DRenderParams p = rp;
     p.stack_depth = sc.max_stack < 1 ? 1 : (sc.max_stack > kStackDepth ? kStackDepth : sc.max_stack);
-    const size_t lds = ((size_t)p.stack_depth * sizeof(StackEntry) + 4 * kLaneFloats + (fits ? 0 : 20)) * kBlock + geomBytes;
+    const size_t lds = ((size_t)p.stack_depth * sizeof(StackEntry) + 4 * kLaneFloats + (fits ? 0 : 32)) * kBlock + geomBytes;
     if (fits && lds > kLdsBlockBytes) return hipErrorInvalidValue; // the host's residency decision uses the same sum
     const bool count = rp.counters != nullptr;
     static const bool debug = getenv("PTAMD_DEBUG") != nullptr;
