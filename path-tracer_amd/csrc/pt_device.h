@@ -394,6 +394,7 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
     int sp = 0, bot = 0;     // own stack entries are rows [bot, sp)
     int cur = valid ? me.root : kDone;
     int cool = 0;
+    const int leafMin = (me.flags & 16u) ? 65 : 0; // an instance that few rays reach: leaf holders wait for the node holders
     auto pop = [&]() {
         if (sp > bot) {
             --sp; cur = (int)stack[sp * BLOCK + slot];
@@ -401,15 +402,17 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
             bound = fminf(bound, __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(&coop.res[waveBase + owner]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
         } else cur = kDone;
     };
-    // One loop trip is either a node step for every lane that holds an inner node or, when no lane holds one, a leaf
-    // pass for every lane that holds a leaf: the branch is wave-uniform, so the two bodies are never issued for a partial
-    // wave in the same trip (the point of "while-while"). Leaf holders wait: a leaf pass with few lanes costs more than
-    // it lets them gain (measured against "whichever group is larger": +5 % on a 7680-triangle mesh among primitives).
+    // One loop trip is either a node step for every lane that holds an inner node or a leaf pass for every lane that
+    // holds a leaf, whichever group is larger: the branch is wave-uniform, so the two bodies are never issued for a
+    // partial wave in the same trip (the point of "while-while"). For an instance that few of the scene's rays reach (the
+    // host's estimate, DMesh::flags bit 4) the leaf holders wait until no lane holds an inner node: a leaf pass for three
+    // lanes costs more than it lets them gain (+6 % on a 7680-triangle mesh among primitives), whereas holding the
+    // leaves back on a model that fills the frame costs 28 %.
     for (;;) {
         const bool isInner = (uint32_t)cur < (uint32_t)kDone, isLeaf = cur < 0;
-        const bool anyInner = __ballot(isInner) != 0ull, anyLeaf = __ballot(isLeaf) != 0ull;
-        if (!anyInner && !anyLeaf) break;
-        if (anyInner) {
+        const int nInner = __popcll(__ballot(isInner)), nLeaf = __popcll(__ballot(isLeaf));
+        if (nInner + nLeaf == 0) break;
+        if (nInner > 0 && (nInner >= nLeaf || nLeaf < leafMin)) {
             if (isInner) {
                 if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
                 const float4* n = nodes + (size_t)cur * 4;

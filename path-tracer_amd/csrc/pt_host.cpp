@@ -59,6 +59,7 @@ struct HostMesh {
     Model model;
     BvhResult bvh;
     bool bvh_valid = false;
+    float bmin[3] = { 0, 0, 0 }, bmax[3] = { 0, 0, 0 }; // bounds of the positions, set with the tree
 };
 
 struct HostObject {
@@ -229,6 +230,55 @@ void fill_mesh_matrices(const HostObject& ho, DMesh& dm)
     bool identity = true;
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) identity = identity && dm.m[4 * r + c] == (r == c ? 1.0f : 0.0f) && dm.minv[4 * r + c] == (r == c ? 1.0f : 0.0f);
     dm.flags = identity ? (dm.flags | 8u) : (dm.flags & ~8u);
+}
+// Marks the mesh instances that few of a scene's rays reach (DMesh::flags bit 4), for which the work-sharing walk holds its
+// leaf passes back. Estimate: a random line through a convex body meets a convex body inside it with probability
+// area(inner) / area(outer); an instance is "sparse" when the surface area of its world bounds is under a quarter of that
+// of the bounds of the whole scene. Returns true when a flag changed.
+struct Bounds3 {
+    float lo[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, hi[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    void add(float x, float y, float z) { const float p[3] = { x, y, z }; for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    void add(const Bounds3& b) { if (b.lo[0] <= b.hi[0]) { add(b.lo[0], b.lo[1], b.lo[2]); add(b.hi[0], b.hi[1], b.hi[2]); } }
+    double area() const
+    {
+        if (!(lo[0] <= hi[0])) return 0.0;
+        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+};
+void mark_sparse_meshes(const std::vector<HostObject>& objects, const std::vector<DObject>& rows, std::vector<DMesh>& meshes, std::vector<char>* changed)
+{
+    Bounds3 all; std::vector<double> area(meshes.size(), 0.0);
+    for (size_t i = 0; i < objects.size() && i < rows.size(); ++i) {
+        const HostObject& ho = objects[i];
+        Bounds3 b;
+        if (ho.kind == KIND_MESH) {
+            const DMesh& dm = meshes[(size_t)rows[i].mesh];
+            const float* lo = ho.mesh->bmin; const float* hi = ho.mesh->bmax;
+            if (!(lo[0] <= hi[0])) continue;
+            for (int c = 0; c < 8; ++c) {
+                const float x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
+                b.add(dm.m[0] * x + dm.m[1] * y + dm.m[2] * z + dm.m[3], dm.m[4] * x + dm.m[5] * y + dm.m[6] * z + dm.m[7],
+                      dm.m[8] * x + dm.m[9] * y + dm.m[10] * z + dm.m[11]);
+            }
+            area[(size_t)rows[i].mesh] = b.area();
+        } else {
+            // a sphere's radius, or half a box's diagonal (whatever its rotation), around the centre
+            const float r = ho.kind == KIND_SPHERE ? std::fabs(ho.radius)
+                                                   : 0.5f * std::sqrt(ho.size[0] * ho.size[0] + ho.size[1] * ho.size[1] + ho.size[2] * ho.size[2]);
+            b.add(ho.pos[0] - r, ho.pos[1] - r, ho.pos[2] - r); b.add(ho.pos[0] + r, ho.pos[1] + r, ho.pos[2] + r);
+        }
+        all.add(b);
+    }
+    const double sceneArea = all.area();
+    const char* force = std::getenv("PTAMD_SPARSE_MESHES"); // 0 | 1: no instance / every instance
+    for (size_t m = 0; m < meshes.size(); ++m) {
+        bool sparse = std::isfinite(sceneArea) && sceneArea > 0.0 && area[m] < 0.25 * sceneArea;
+        if (force) sparse = force[0] == '1';
+        const uint32_t flags = sparse ? (meshes[m].flags | 16u) : (meshes[m].flags & ~16u);
+        if (changed && flags != meshes[m].flags) (*changed)[m] = 1;
+        meshes[m].flags = flags;
+    }
 }
 bool group_samples_images(const ptamd_pbr& g)
 {
@@ -534,6 +584,12 @@ int ptamd_scene_commit(ptamd_scene* s)
             }
             s->edits[i] = 0;
         }
+        {
+            std::vector<char> changed(s->h_meshes.size(), 0);
+            mark_sparse_meshes(s->objects, s->h_objects, s->h_meshes, &changed);
+            for (size_t m = 0; m < changed.size(); ++m)
+                if (changed[m]) { PT_HIP(hipMemcpyAsync(s->d_meshes.ptr + m, &s->h_meshes[m], sizeof(DMesh), hipMemcpyHostToDevice, g_stream)); ++s->row_updates; }
+        }
         PT_HIP(hipStreamSynchronize(g_stream)); // the copies read host rows that the next edit may change
         s->committed = true;
         s->last_commit_seconds = seconds_since(t_begin);
@@ -565,6 +621,11 @@ int ptamd_scene_commit(ptamd_scene* s)
                 const Model& md = hm.model;
                 const auto t0 = std::chrono::steady_clock::now();
                 hm.bvh = build_bvh(md.positions.data(), md.group.data(), md.num_faces(), maxDepth);
+                for (int k = 0; k < 3; ++k) { hm.bmin[k] = 3.0e38f; hm.bmax[k] = -3.0e38f; }
+                for (size_t i = 0; i < md.positions.size(); ++i) { // (a NaN coordinate leaves the bounds alone)
+                    const int k = (int)(i % 3);
+                    hm.bmin[k] = std::min(hm.bmin[k], md.positions[i]); hm.bmax[k] = std::max(hm.bmax[k], md.positions[i]);
+                }
                 if (hm.bvh.depth > maxDepth) return fail(PTAMD_ERR_LIMIT, "BVH deeper than the traversal stack");
                 build_wide(hm.bvh);
                 hm.bvh_valid = true;
@@ -685,6 +746,7 @@ int ptamd_scene_commit(ptamd_scene* s)
     if (tris.size() >= (size_t(1) << 30)) return fail(PTAMD_ERR_LIMIT, "scene has too many triangles (limit 2^30 - 1 over all distinct meshes)");
     std::memset(&s->dscene, 0, sizeof(DScene)); // nothing may point at the buffers released next
     s->release();
+    mark_sparse_meshes(s->objects, objects, meshes, nullptr);
     if (int rc = s->d_objects.upload(objects)) return rc;
     if (int rc = s->d_meshes.upload(meshes)) return rc;
     if (int rc = s->d_materials.upload(materials)) return rc;

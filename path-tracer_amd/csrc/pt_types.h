@@ -45,7 +45,8 @@ struct DMesh {
     int32_t root;         // child reference of the root (see DNode)
     uint32_t flags;       // bit 0: some group uses alpha MASK; bit 1: some group samples a texture; bit 2: the mesh is
                           // traversed through DWideNode (node_base then counts 80-byte nodes, the root is node 0); bit 3: the
-                          // instance matrix is the identity (M x = x exactly: the kernels skip the products)
+                          // instance matrix is the identity (M x = x exactly: the kernels skip the products); bit 4: few of the
+                          // scene's rays reach this instance (the work-sharing walk then holds its leaf passes back)
     uint32_t pad;
 };
 

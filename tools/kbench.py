@@ -31,6 +31,9 @@ def main():
         "glass_mirror": (presets.glass_mirror(1920, 1080), 32),
         "blob_mixed": (presets.mixed("tests/golden/blob.glb", 1920, 1080, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0)), 8),
     }
+    if "dragon" in args.scenes.split(","):  # the reference's 100 000-triangle model alone under the sky colour
+        table["dragon"] = ({"film": (1920, 1080), "camera": {"pos": (28., 12., -60.), "rot": (0., 180., 0.), "fov": 45., "near": .1, "far": 100.},
+                            "objects": [{"type": "mesh", "path": "tests/golden/chinese_dragon.glb", "pos": (0, 0, 0), "rot": (-90., 0, 0), "scale": (1, 1.2, 0.8)}]}, 6)
     for name, (rings, segments) in {"bumpy_1m": (500, 1000), "bumpy_280": (10, 14)}.items():
         if name not in args.scenes.split(","):
             continue
