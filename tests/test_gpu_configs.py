@@ -418,6 +418,28 @@ def test_wide_nodes_agree_with_binary_nodes(gpu, monkeypatch):
         assert (np.abs(hg[both, 1] - hw[both, 1]) <= 1e-6 * np.abs(hw[both, 1])).mean() >= 0.999
 
 
+def test_leaf_pass_rule_changes_the_schedule_not_the_image(gpu, monkeypatch):
+    """The work-sharing walk holds its leaf passes back for mesh instances that few rays reach (the host's estimate per
+    instance; PTAMD_SPARSE_MESHES forces it off or on). Closest hits are settled by an atomic minimum with a fixed tie
+    rule, so the two schedules must give the same film bit for bit; on a small mesh among primitives the estimate picks
+    the held-back form by itself, which runs fewer (fuller) leaf passes."""
+    scene = presets.mixed("tests/golden/blob.glb", 160, 120, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
+    out = {}
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("PTAMD_SPARSE_MESHES", raising=False)
+        else:
+            monkeypatch.setenv("PTAMD_SPARSE_MESHES", mode)
+        pt, cam = gpu.build_scene(scene)
+        film = gpu.Film(160, 120)
+        gpu.Render(cam, pt, film, 6, 8, seed=5, count=True)
+        out[mode] = (film.Accum(), gpu.RenderStats())
+    assert np.array_equal(out["0"][0].view(np.uint32), out["1"][0].view(np.uint32))
+    assert np.array_equal(out["0"][0].view(np.uint32), out[None][0].view(np.uint32))
+    assert out["1"][1]["tris"] > 0 and out["1"][1]["tri_trips"] < 0.8 * out["0"][1]["tri_trips"]
+    assert out[None][1]["tri_trips"] == out["1"][1]["tri_trips"]  # the estimate marks this instance by itself
+
+
 def test_quads_far_from_the_origin(gpu, monkeypatch):
     """The Cornell mesh moved 10^4 units from the origin, where a float coordinate resolves 10^-3: faces whose fourth
     corner no longer sits within rounding of b + c - a must not be paired, and whatever is paired must give the closest
