@@ -357,16 +357,16 @@ struct Coop { unsigned long long* res; uint32_t* mail; }; // LDS, one entry per 
 #define PT_WIDE_LEAF_BIAS 1 // a leaf trip runs when more than 1/PT_WIDE_LEAF_BIAS as many lanes wait for one as for a node
 #endif
 #ifndef PT_STEAL_AFTER_LEAVES
-#define PT_STEAL_AFTER_LEAVES 1
+#define PT_STEAL_AFTER_LEAVES 1 // the eight-wide walk runs steal rounds after leaf trips too, not only after node trips
 #endif
 #ifndef PT_SHARE_LEAVES
-#define PT_SHARE_LEAVES 1
+#define PT_SHARE_LEAVES 1 // ... and hands out single hit leaves of lanes that hold several
 #endif
 #ifndef PT_SPLIT_GROUPS
 #define PT_SPLIT_GROUPS 1 // the eight-wide walk also hands out parts of current groups
 #endif
 #ifndef PT_STEAL_COOL
-#define PT_STEAL_COOL 0  // node trips to wait after a steal round
+#define PT_STEAL_COOL 0  // node trips to wait after a steal round of the two-child walk (1 costs 6 %, 3 costs 16 %: the rounds pay)
 #endif
 
 PT_DEV int rank_in(unsigned long long mask) // set bits of mask below this lane

@@ -54,7 +54,7 @@ PT_DEV void add_sample(f3& acc, f3 c)
 constexpr uint32_t kFlagRoulette = 2u; // PTAMD_FLAG_RUSSIAN_ROULETTE
 constexpr int kNumCounters = 10;        // fields of ptamd_stats, in order
 #ifndef PT_PRIMARY_CACHE
-#define PT_PRIMARY_CACHE 1
+#define PT_PRIMARY_CACHE 1 // work-sharing builds keep the camera ray's hit per pixel after the first sample of a launch
 #endif
 #ifndef PT_WAVES
 #define PT_WAVES 5
