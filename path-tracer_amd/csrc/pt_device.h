@@ -458,9 +458,11 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
                 o.x = __shfl(o.x, src, 64); o.y = __shfl(o.y, src, 64); o.z = __shfl(o.z, src, 64);
                 d.x = __shfl(d.x, src, 64); d.y = __shfl(d.y, src, 64); d.z = __shfl(d.z, src, 64);
                 tMinObj = __shfl(tMinObj, src, 64); bound = __shfl(bound, src, 64); owner = __shfl(owner, src, 64);
+                // (the reciprocals come along too: cross-lane reads run beside the vector ALU, which is the busy unit)
+                inv.x = __shfl(inv.x, src, 64); inv.y = __shfl(inv.y, src, 64); inv.z = __shfl(inv.z, src, 64);
+                oi.x = __shfl(oi.x, src, 64); oi.y = __shfl(oi.y, src, 64); oi.z = __shfl(oi.z, src, 64);
                 const int sBot = __shfl(bot, src, 64);
                 if (thief) {
-                    inv = inverse(d); oi = o * inv;
                     cur = (int)stack[sBot * BLOCK + waveBase + src];
                     sp = 0; bot = 0;
                 }
@@ -672,8 +674,11 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
                 d.x = __shfl(d.x, src, 64); d.y = __shfl(d.y, src, 64); d.z = __shfl(d.z, src, 64);
                 tMinObj = __shfl(tMinObj, src, 64); bound = __shfl(bound, src, 64); owner = __shfl(owner, src, 64);
                 oBase = __shfl(oBase, src, 64); oBits = __shfl(oBits, src, 64);
+                // (the reciprocals and the octant come along too: cross-lane reads run beside the vector ALU, the busy unit)
+                inv.x = __shfl(inv.x, src, 64); inv.y = __shfl(inv.y, src, 64); inv.z = __shfl(inv.z, src, 64);
+                oct = (uint32_t)__shfl((int)oct, src, 64);
                 if (thief) {
-                    inv = inverse(d); oct = octant(inv);
+
                     sp = 0; bot = 0;
                     if (oBits & 0x80000000u) { // one leaf: every meta byte describes it, so any slot number finds it
                         gBase = 0u; gBits = 0u;
