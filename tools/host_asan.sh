@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   (cd path-tracer_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O1 -g -fPIC -Wall -Wno-unused-function -fno-slp-vectorize \
      -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -shared csrc/pt_kernels.hip csrc/pt_host.cpp csrc/bvh_build.cpp \
      csrc/gltf_loader.cpp csrc/jpeg_decode.cpp -lz -lpthread -o dev/libptamd.so
-   /opt/rocm/lib/llvm/bin/clang++ -std=c++17 -O1 -g -fsanitize=address,undefined host/ptamd_cli.cpp -o dev/ptamd_cli_asan -I. -Ldev -lptamd -lz -Wl,-rpath,'$ORIGIN')
+   /opt/rocm/lib/llvm/bin/clang++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-gpu-sanitize host/ptamd_cli.cpp -o dev/ptamd_cli_asan -I. -Ldev -lptamd -lz -Wl,-rpath,'$ORIGIN')
   exit 0
 fi
 shift
