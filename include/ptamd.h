@@ -156,6 +156,11 @@ int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3]);
  * the top, OpenGL cubemap orientation; radiance = texel / 255 * intensity (nearest texel, no sRGB decode).
  * faces == NULL or face_size <= 0 removes it. Takes effect at once; no commit needed. */
 int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const faces[6], float intensity);
+/* The same with float radiance (an HDR map; no reference counterpart either): each face is face_size x face_size texels
+ * of three floats (r, g, b), row 0 at the top; a miss returns the nearest texel as it is -- no intensity factor, no upper
+ * bound (Film::AddSample still clips each sample's luminance at 12, Film.cpp:38-43). Replaces an RGBA8 map and vice
+ * versa. faces == NULL or face_size <= 0 removes it. Limit 4096 x 4096 per face (1.6 GB on the device). */
+int ptamd_scene_set_skybox_f32(ptamd_scene* s, int face_size, const float* const faces[6]);
 /* Flattens the object list into SoA device buffers, builds and linearises the per-mesh BVHs
  * (replaces Mesh::BuildBVH, Mesh.cpp:289-397) and uploads. Re-callable after edits; trees are built once per
  * mesh, and edits that leave the geometry alone rewrite single table rows (see ptamd_scene_get_info). */
@@ -189,6 +194,12 @@ int ptamd_model_load_ex(const char* path, uint32_t flags, ptamd_model** out);
 int ptamd_model_desc(const ptamd_model* m, ptamd_mesh_desc* out); /* pointers stay valid until ptamd_model_free */
 const char* ptamd_model_group_name(const ptamd_model* m, uint32_t group);
 void ptamd_model_free(ptamd_model* m);
+/* One encoded image (PNG or JPEG) decoded as the loader decodes the images of a model: RGBA8, row 0 first -- what
+ * tinygltf's LoadImageData gets from stb_image with four requested channels (contrib/include/tiny_gltf.h:2617-2722,
+ * compiled by ModelLoader.cpp:1-7). *rgba (width * height * 4 bytes) belongs to the caller until ptamd_image_free.
+ * Needs no GPU. */
+int ptamd_image_decode(const uint8_t* bytes, size_t size, int* width, int* height, uint8_t** rgba);
+void ptamd_image_free(uint8_t* rgba);
 
 /* ---- film: Film.h:19-61 -------------------------------------------------------------------- */
 int ptamd_film_create(int width, int height, ptamd_film** out);            /* Film(w,h) */

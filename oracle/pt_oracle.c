@@ -236,6 +236,7 @@ struct po_scene {
     object_t* objs; int nobjs, cap;
     v3 background; /* PathTracer.h:21 */
     int sky_size; uint8_t* sky; float sky_intensity; /* extension: cubemap, 6 * size * size * 4 bytes */
+    float* sky_f32;                                  /* or float radiance, 6 * size * size * 3 floats */
 };
 
 typedef struct { po_counters c; } tls_counters;
@@ -259,16 +260,27 @@ void po_scene_destroy(po_scene* s)
 {
     if (!s) return;
     for (int i = 0; i < s->nobjs; ++i) mesh_free(s->objs[i].mesh);
-    free(s->objs); free(s->sky); free(s);
+    free(s->objs); free(s->sky); free(s->sky_f32); free(s);
 }
 void po_scene_set_skybox(po_scene* s, int size, const uint8_t* const faces[6], float intensity)
 {
     free(s->sky); s->sky = NULL; s->sky_size = 0;
+    free(s->sky_f32); s->sky_f32 = NULL;
     if (!faces || size <= 0) return;
     size_t fb = (size_t)size * size * 4;
     s->sky = (uint8_t*)malloc(6 * fb);
     for (int f = 0; f < 6; ++f) memcpy(s->sky + f * fb, faces[f], fb);
     s->sky_size = size; s->sky_intensity = intensity;
+}
+void po_scene_set_skybox_f32(po_scene* s, int size, const float* const faces[6])
+{
+    free(s->sky); s->sky = NULL; s->sky_size = 0;
+    free(s->sky_f32); s->sky_f32 = NULL;
+    if (!faces || size <= 0) return;
+    size_t fn = (size_t)size * size * 3;
+    s->sky_f32 = (float*)malloc(6 * fn * sizeof(float));
+    for (int f = 0; f < 6; ++f) memcpy(s->sky_f32 + f * fn, faces[f], fn * sizeof(float));
+    s->sky_size = size;
 }
 /* Extension (no reference counterpart): miss radiance from a cubemap, OpenGL face selection and orientation. */
 static v3 sky_lookup(const po_scene* s, v3 d)
@@ -282,6 +294,7 @@ static v3 sky_lookup(const po_scene* s, v3 d)
     int n = s->sky_size;
     int x = (int)(u * (float)n), y = (int)(v * (float)n);
     x = x < 0 ? 0 : (x > n - 1 ? n - 1 : x); y = y < 0 ? 0 : (y > n - 1 ? n - 1 : y);
+    if (s->sky_f32) { const float* r = s->sky_f32 + (((size_t)face * n + y) * n + x) * 3; return V3(r[0], r[1], r[2]); }
     const uint8_t* t = s->sky + (((size_t)face * n + y) * n + x) * 4;
     return scl3(V3((float)t[0] / 255.0f, (float)t[1] / 255.0f, (float)t[2] / 255.0f), s->sky_intensity);
 }
@@ -829,7 +842,7 @@ static v3 trace_ray(const po_scene* s, ray_t ray, int depth, int albedoOnly, rng
     const float kTMin = 1e-4f;
     hit_t best; memset(&best, 0, sizeof best);
     float closestT;
-    if (!closest_hit(s, &ray, &best, &closestT)) return s->sky ? sky_lookup(s, ray.d) : s->background;
+    if (!closest_hit(s, &ray, &best, &closestT)) return s->sky_size > 0 ? sky_lookup(s, ray.d) : s->background;
     const po_material* m = &best.mat;
     v3 albedo = V3(m->albedo[0], m->albedo[1], m->albedo[2]);
     if (albedoOnly) { /* PathTracer.cpp:62-71 */

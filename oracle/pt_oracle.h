@@ -112,6 +112,7 @@ void po_render(const po_scene*, const po_camera*, int w, int h, float* accum, ui
 /* Cubemap: 6 faces (+x, -x, +y, -y, +z, -z), each size x size RGBA8, row 0 = top; OpenGL face orientation,
  * nearest texel, texel / 255 * intensity replaces the constant miss radiance. faces == NULL disables it. */
 void po_scene_set_skybox(po_scene*, int size, const uint8_t* const faces[6], float intensity);
+void po_scene_set_skybox_f32(po_scene*, int size, const float* const faces[6]); /* float rgb texels, returned as they are */
 /* po_render with flags (PO_FLAG_RUSSIAN_ROULETTE: from the 3rd bounce on a path survives with probability
  * q = clamp(max(throughput), 0.05, 1) drawn from slot 7 of the bounce's random numbers, and is divided by q). */
 void po_render_ext(const po_scene*, const po_camera*, int w, int h, float* accum, uint32_t* samples,

@@ -74,6 +74,7 @@ def lib():
                                 C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32] + [C.c_int] * 5 + [C.POINTER(Counters)]
         L.po_render_ext.argtypes = L.po_render.argtypes + [C.c_uint32]
         L.po_scene_set_skybox.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_float]
+        L.po_scene_set_skybox_f32.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.po_film_add_sample.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         L.po_film_resolve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.po_pcg_hash.argtypes = [C.c_uint32]
@@ -154,9 +155,15 @@ class Scene:
             self.set_skybox(scene["skybox"]["faces"], scene["skybox"].get("intensity", 1.0))
 
     def set_skybox(self, faces, intensity=1.0):
-        """Extension (no reference counterpart): faces = (6, N, N, 4) uint8 in +x -x +y -y +z -z order, or None."""
+        """Extension (no reference counterpart): faces = (6, N, N, 4) uint8 in +x -x +y -y +z -z order, (6, N, N, 3) float32
+        radiance (intensity unused), or None."""
         if faces is None:
             lib().po_scene_set_skybox(self.h, 0, None, 0.0)
+            return
+        if np.asarray(faces).dtype != np.uint8:
+            f = np.ascontiguousarray(faces, np.float32)
+            ptrs = (C.c_void_p * 6)(*[f[i].ctypes.data for i in range(6)])
+            lib().po_scene_set_skybox_f32(self.h, f.shape[1], ptrs)
             return
         f = np.ascontiguousarray(faces, np.uint8)
         ptrs = (C.c_void_p * 6)(*[f[i].ctypes.data for i in range(6)])

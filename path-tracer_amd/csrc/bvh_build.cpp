@@ -5,7 +5,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <limits>
+#include <mutex>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 
@@ -325,16 +328,31 @@ BvhResult build_bvh(const float* P, const int32_t* group, uint32_t n, int max_de
         const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         std::vector<std::thread> pool;
         std::atomic<size_t> next{ 0 };
+        // An exception in a worker (out of memory) must not leave its thread through the top of its stack: the first one is
+        // kept, the remaining tasks are skipped, and it is thrown again here once every thread has been joined.
+        std::exception_ptr failure;
+        std::mutex failureLock;
         auto work = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < b.tasks.size();) {
-                Builder::Task& t = b.tasks[i];
-                Box3 box;
-                t.ref = b.build(t.out, t.start, t.count, t.depth, box);
+            try {
+                for (size_t i; (i = next.fetch_add(1)) < b.tasks.size();) {
+                    Builder::Task& t = b.tasks[i];
+                    Box3 box;
+                    t.ref = b.build(t.out, t.start, t.count, t.depth, box);
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> g(failureLock);
+                if (!failure) failure = std::current_exception();
+                next.store(b.tasks.size());
             }
         };
-        for (unsigned i = 1; i < hw; ++i) pool.emplace_back(work);
+        try {
+            for (unsigned i = 1; i < hw; ++i) pool.emplace_back(work);
+        } catch (const std::system_error&) {
+            // no more threads to be had (process or thread limit): the ones that started and this thread do the work
+        }
         work();
         for (std::thread& th : pool) th.join();
+        if (failure) std::rethrow_exception(failure);
         for (Builder::Task& t : b.tasks) {
             const int32_t nodeOff = (int32_t)top.nodes.size();
             const uint32_t slotOff = (uint32_t)top.slots.size();

@@ -242,6 +242,10 @@ void decode_image_rgba(const uint8_t* data, size_t size, int& w, int& h, std::ve
     else decode_png_rgba(data, size, w, h, rgba);
 }
 
+} // namespace
+void decode_image(const uint8_t* data, size_t size, int& w, int& h, std::vector<uint8_t>& rgba) { decode_image_rgba(data, size, w, h, rgba); }
+namespace {
+
 struct Doc {
     JPtr root;
     std::vector<std::vector<uint8_t>> buffers;

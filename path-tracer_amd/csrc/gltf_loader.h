@@ -29,5 +29,8 @@ enum : uint32_t {
 // Throws std::runtime_error with the reference's messages where it has them. flags = 0 is the reference's loader.
 void load_gltf(const std::string& path, Model& out, uint32_t flags = 0);
 void load_obj(const std::string& path, Model& out);
+// One encoded image (PNG or JPEG, told apart by signature) as RGBA8, row 0 first: what tinygltf's LoadImageData gets from
+// stb_image with four requested channels (contrib/include/tiny_gltf.h:2617-2722). Throws std::runtime_error.
+void decode_image(const uint8_t* data, size_t size, int& w, int& h, std::vector<uint8_t>& rgba);
 
 } // namespace ptamd

@@ -239,6 +239,14 @@ private:
         for (int i = 0; i < ncomp_; ++i) if (hmax_ % comp_[i].h || vmax_ % comp_[i].v) bad("sampling factors do not divide");
         mcux_ = (width_ + hmax_ * 8 - 1) / (hmax_ * 8);
         mcuy_ = (height_ + vmax_ * 8 - 1) / (vmax_ * 8);
+        // The planes below are sized by the header alone. Entropy-coded data spends at least one bit on every 8x8 block
+        // (its DC code), so a file cannot describe more than 8 blocks per remaining byte; a header that claims 64 times
+        // what its bytes could hold (truncated files still decode, as in stb_image) is refused before anything is allocated.
+        {
+            uint64_t blocks = 0;
+            for (int i = 0; i < ncomp_; ++i) blocks += (uint64_t)mcux_ * comp_[i].h * (uint64_t)mcuy_ * comp_[i].v;
+            if (blocks > 64ull * (uint64_t)(end_ - p_) + 4096ull) bad("frame far larger than the file's data");
+        }
         for (int i = 0; i < ncomp_; ++i) {
             Component& c = comp_[i];
             c.x = (width_ * c.h + hmax_ - 1) / hmax_;

@@ -102,7 +102,7 @@ struct ptamd_scene {
     DevBuf<DObject> d_objects; DevBuf<DMesh> d_meshes; DevBuf<DMaterial> d_materials;
     DevBuf<DNode> d_nodes; DevBuf<DWideNode> d_wide; DevBuf<float> d_lds_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
-    DevBuf<uint32_t> d_sky; int sky_size = 0; float sky_intensity = 1.0f;
+    DevBuf<uint32_t> d_sky; int sky_size = 0; float sky_intensity = 1.0f; int sky_format = 0;
     unsigned long long* d_counters = nullptr; // this scene's PTAMD_FLAG_COUNT tallies (allocated by its first counting render)
     DScene dscene;
     void release() // what commit rebuilds; the sky map is uploaded by its own call and outlives commits
@@ -498,28 +498,54 @@ int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3])
     return PTAMD_OK;
 }
 
-int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const faces[6], float intensity)
+// Both sky entry points end here: `tex` holds the six faces in device form (one word per RGBA8 texel, four per float texel).
+static int upload_sky(ptamd_scene* s, int face_size, const std::vector<uint32_t>& tex, int format, float intensity)
 {
-    if (int rc = check_scene(s)) return rc;
-    if (!faces || face_size <= 0) {
-        s->d_sky.release(); s->sky_size = 0;
-        s->dscene.sky = nullptr; s->dscene.sky_size = 0;
-        return PTAMD_OK;
-    }
-    if (int rc = need_init()) return rc;
-    if (face_size > 8192) return fail(PTAMD_ERR_LIMIT, "skybox faces are limited to 8192 x 8192");
-    for (int f = 0; f < 6; ++f) if (!faces[f]) return fail(PTAMD_ERR_ARG, "null skybox face");
-    const size_t n = (size_t)face_size * face_size;
-    std::vector<uint32_t> tex(6 * n);
-    for (int f = 0; f < 6; ++f) std::memcpy(tex.data() + f * n, faces[f], n * 4);
     if (int rc = s->d_sky.upload(tex)) { // the old map is gone and the new one did not arrive: fall back to the constant background
         s->d_sky.release(); s->sky_size = 0;
         s->dscene.sky = nullptr; s->dscene.sky_size = 0;
         return rc;
     }
-    s->sky_size = face_size; s->sky_intensity = intensity;
-    s->dscene.sky = s->d_sky.ptr; s->dscene.sky_size = face_size; s->dscene.sky_intensity = intensity;
+    s->sky_size = face_size; s->sky_intensity = intensity; s->sky_format = format;
+    s->dscene.sky = s->d_sky.ptr; s->dscene.sky_size = face_size; s->dscene.sky_intensity = intensity; s->dscene.sky_format = format;
     return PTAMD_OK;
+}
+static int clear_sky(ptamd_scene* s)
+{
+    s->d_sky.release(); s->sky_size = 0;
+    s->dscene.sky = nullptr; s->dscene.sky_size = 0;
+    return PTAMD_OK;
+}
+
+int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const faces[6], float intensity)
+{
+    if (int rc = check_scene(s)) return rc;
+    if (!faces || face_size <= 0) return clear_sky(s);
+    if (int rc = need_init()) return rc;
+    if (face_size > 8192) return fail(PTAMD_ERR_LIMIT, "skybox faces are limited to 8192 x 8192");
+    for (int f = 0; f < 6; ++f) if (!faces[f]) return fail(PTAMD_ERR_ARG, "null skybox face");
+    const size_t n = (size_t)face_size * face_size;
+    try {
+        std::vector<uint32_t> tex(6 * n);
+        for (int f = 0; f < 6; ++f) std::memcpy(tex.data() + f * n, faces[f], n * 4);
+        return upload_sky(s, face_size, tex, 0, intensity);
+    } catch (const std::exception& e) { return fail(PTAMD_ERR_LIMIT, e.what()); }
+}
+
+int ptamd_scene_set_skybox_f32(ptamd_scene* s, int face_size, const float* const faces[6])
+{
+    if (int rc = check_scene(s)) return rc;
+    if (!faces || face_size <= 0) return clear_sky(s);
+    if (int rc = need_init()) return rc;
+    if (face_size > 4096) return fail(PTAMD_ERR_LIMIT, "float skybox faces are limited to 4096 x 4096");
+    for (int f = 0; f < 6; ++f) if (!faces[f]) return fail(PTAMD_ERR_ARG, "null skybox face");
+    const size_t n = (size_t)face_size * face_size;
+    try {
+        std::vector<uint32_t> tex(6 * n * 4, 0u); // rgb + one unused word: a texel is one 16-byte read
+        for (int f = 0; f < 6; ++f)
+            for (size_t p = 0; p < n; ++p) std::memcpy(&tex[(f * n + p) * 4], faces[f] + 3 * p, 12);
+        return upload_sky(s, face_size, tex, 1, 1.0f);
+    } catch (const std::exception& e) { return fail(PTAMD_ERR_LIMIT, e.what()); }
 }
 
 
@@ -540,10 +566,24 @@ static void append_lds_nodes(const std::vector<DNode>& nodes, std::vector<float>
     }
 }
 
+static int commit_scene(ptamd_scene* s);
 int ptamd_scene_commit(ptamd_scene* s)
 {
     if (int rc = check_scene(s)) return rc;
     if (int rc = need_init()) return rc;
+    // the tree builders and the flattening allocate and start threads: nothing they throw may cross the C boundary
+    try {
+        return commit_scene(s);
+    } catch (const std::bad_alloc&) {
+        s->committed = false;
+        return fail(PTAMD_ERR_LIMIT, "out of host memory while committing the scene");
+    } catch (const std::exception& e) {
+        s->committed = false;
+        return fail(PTAMD_ERR_STATE, e.what());
+    }
+}
+static int commit_scene(ptamd_scene* s)
+{
     const auto t_begin = std::chrono::steady_clock::now();
     auto seconds_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     if (!s->structure_dirty && s->h_objects.size() == s->objects.size()) {
@@ -769,7 +809,7 @@ int ptamd_scene_commit(ptamd_scene* s)
     ds.shade = reinterpret_cast<const float4*>(s->d_shade.ptr);
     ds.groups = s->d_groups.ptr; ds.images = s->d_images.ptr; ds.texels = s->d_texels.ptr;
     std::memcpy(ds.background, s->background, 12);
-    ds.sky = s->sky_size ? s->d_sky.ptr : nullptr; ds.sky_size = s->sky_size; ds.sky_intensity = s->sky_intensity;
+    ds.sky = s->sky_size ? s->d_sky.ptr : nullptr; ds.sky_size = s->sky_size; ds.sky_intensity = s->sky_intensity; ds.sky_format = s->sky_format;
     ds.num_nodes = (uint32_t)nodes.size(); ds.num_tris = (uint32_t)tris.size();
     ds.max_stack = 1; // rows of the per-lane traversal stack the deepest walk of this scene needs
     for (const HostObject& ho : s->objects)
@@ -829,6 +869,22 @@ const char* ptamd_model_group_name(const ptamd_model* m, uint32_t group)
     return m->model.group_names[group].c_str();
 }
 void ptamd_model_free(ptamd_model* m) { delete m; }
+
+int ptamd_image_decode(const uint8_t* bytes, size_t size, int* width, int* height, uint8_t** rgba)
+{
+    if (!bytes || !width || !height || !rgba) return fail(PTAMD_ERR_ARG, "null argument");
+    *rgba = nullptr; *width = *height = 0;
+    try {
+        std::vector<uint8_t> px; int w = 0, h = 0;
+        decode_image(bytes, size, w, h, px);
+        uint8_t* out = static_cast<uint8_t*>(std::malloc(std::max<size_t>(1, px.size())));
+        if (!out) return fail(PTAMD_ERR_LIMIT, "out of memory");
+        std::memcpy(out, px.data(), px.size());
+        *rgba = out; *width = w; *height = h;
+        return PTAMD_OK;
+    } catch (const std::exception& e) { return fail(PTAMD_ERR_IO, e.what()); }
+}
+void ptamd_image_free(uint8_t* rgba) { std::free(rgba); }
 
 // ------------------------------------------------------------------------------- film
 static int film_alloc(ptamd_film* f, int w, int h)

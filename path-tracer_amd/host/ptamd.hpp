@@ -157,6 +157,7 @@ public:
     void SetBackgroundColour(const vec3& c) { check(ptamd_scene_set_background(mScene, &c.x)); }
     // Cubemap miss radiance (not in the reference): six faceSize x faceSize RGBA8 faces, +x -x +y -y +z -z; null removes it.
     void SetSkybox(int faceSize, const uint8_t* const faces[6], float intensity = 1.0f) { check(ptamd_scene_set_skybox(mScene, faceSize, faces, intensity)); }
+    void SetSkyboxFloat(int faceSize, const float* const faces[6]) { check(ptamd_scene_set_skybox_f32(mScene, faceSize, faces)); } // float rgb radiance per texel
     // Flatten + BVH + upload; call after building or editing the scene, before the next frame.
     void Commit() { check(ptamd_scene_commit(mScene)); }
     ptamd_scene* Handle() { return mScene; }

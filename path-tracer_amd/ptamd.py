@@ -78,8 +78,8 @@ EXPORTS = [
     "ptamd_pbr_default", "ptamd_scene_create", "ptamd_scene_destroy", "ptamd_scene_clear",
     "ptamd_scene_object_count", "ptamd_scene_add_sphere", "ptamd_scene_add_box", "ptamd_scene_add_mesh",
     "ptamd_scene_add_mesh_file", "ptamd_scene_set_transform", "ptamd_scene_set_radius",
-    "ptamd_scene_set_material", "ptamd_scene_set_mesh_group", "ptamd_scene_set_background", "ptamd_scene_set_skybox",
-    "ptamd_scene_commit", "ptamd_scene_get_info", "ptamd_model_load", "ptamd_model_load_ex", "ptamd_model_desc", "ptamd_model_group_name", "ptamd_model_free",
+    "ptamd_scene_set_material", "ptamd_scene_set_mesh_group", "ptamd_scene_set_background", "ptamd_scene_set_skybox", "ptamd_scene_set_skybox_f32",
+    "ptamd_scene_commit", "ptamd_scene_get_info", "ptamd_model_load", "ptamd_model_load_ex", "ptamd_model_desc", "ptamd_model_group_name", "ptamd_model_free", "ptamd_image_decode", "ptamd_image_free",
     "ptamd_film_create", "ptamd_film_create_external", "ptamd_film_destroy", "ptamd_film_resize",
     "ptamd_film_reset", "ptamd_film_size", "ptamd_film_read", "ptamd_film_average",
     "ptamd_film_resolve_rgba8", "ptamd_film_device_ptrs", "ptamd_render", "ptamd_render_tiles", "ptamd_render_stats", "ptamd_render_counted_noalloc",
@@ -124,6 +124,10 @@ def lib():
         L.ptamd_scene_set_mesh_group.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(CPbr)]
         L.ptamd_scene_set_background.argtypes = [vp, f3]
         L.ptamd_scene_set_skybox.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.c_float]
+        L.ptamd_scene_set_skybox_f32.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p)]
+        L.ptamd_image_decode.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(vp)]
+        L.ptamd_image_free.argtypes = [vp]
+        L.ptamd_image_free.restype = None
         L.ptamd_scene_commit.argtypes = [vp]
         L.ptamd_scene_get_info.argtypes = [vp, C.POINTER(CSceneInfo)]
         L.ptamd_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -392,6 +396,18 @@ class PathTracer:
         ptrs = (C.c_void_p * 6)(*[f[i].ctypes.data for i in range(6)])
         check(lib().ptamd_scene_set_skybox(self._h, f.shape[1], ptrs, float(intensity)))
 
+    def SetSkyboxFloat(self, faces):
+        """The same with float radiance (an HDR map): faces is a (6, N, N, 3) float32 array, returned by a miss as it
+        is; None removes it."""
+        if faces is None:
+            check(lib().ptamd_scene_set_skybox_f32(self._h, 0, None))
+            return
+        f = np.ascontiguousarray(faces, np.float32)
+        if f.ndim != 4 or f.shape[0] != 6 or f.shape[1] != f.shape[2] or f.shape[3] != 3:
+            raise ValueError("float skybox faces must be (6, N, N, 3) float32")
+        ptrs = (C.c_void_p * 6)(*[f[i].ctypes.data for i in range(6)])
+        check(lib().ptamd_scene_set_skybox_f32(self._h, f.shape[1], ptrs))
+
     def Commit(self):
         check(lib().ptamd_scene_commit(self._h))
 
@@ -586,7 +602,10 @@ def build_scene(scene, mesh_data=None):
     if "background" in scene:
         pt.SetBackgroundColour(scene["background"])
     if scene.get("skybox") is not None:
-        pt.SetSkybox(scene["skybox"]["faces"], scene["skybox"].get("intensity", 1.0))
+        if np.asarray(scene["skybox"]["faces"]).dtype == np.uint8:
+            pt.SetSkybox(scene["skybox"]["faces"], scene["skybox"].get("intensity", 1.0))
+        else:
+            pt.SetSkyboxFloat(scene["skybox"]["faces"])
     pt.Commit()
     c = scene["camera"]
     cam = Camera(scene["film"], c["pos"], c["rot"])
@@ -594,6 +613,17 @@ def build_scene(scene, mesh_data=None):
     cam.SetNearPlane(c.get("near", 0.1))
     cam.SetFarPlane(c.get("far", 100.0))
     return pt, cam
+
+
+def decode_image(data):
+    """An encoded PNG or JPEG (bytes) as the loader decodes a model's images: (H, W, 4) uint8. Needs no GPU."""
+    w, h, px = C.c_int(), C.c_int(), C.c_void_p()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    check(lib().ptamd_image_decode(C.cast(buf, C.c_void_p), len(data), C.byref(w), C.byref(h), C.byref(px)))
+    try:
+        return np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+    finally:
+        lib().ptamd_image_free(px)
 
 
 LOAD_NODE_TRANSFORMS = 1

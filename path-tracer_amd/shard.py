@@ -40,6 +40,13 @@ def reduce_film(accum, samples=None, dst=0, all_ranks=False):
     for t in (accum, samples):
         if t is None:
             continue
+        if t.is_cuda and dist.get_backend() == "gloo":
+            # gloo has no reduce on device tensors (two ranks sharing one GPU in tests): sum on the host, copy back
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            if all_ranks or dist.get_rank() == dst:
+                t.copy_(h)
+            continue
         if all_ranks:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         else:

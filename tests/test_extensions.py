@@ -62,6 +62,25 @@ def test_uniform_cubemap_is_the_constant_background():
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
 
 
+def test_float_cubemap_is_returned_as_it_is():
+    """The float (HDR) form of the sky map: a constant 0.2 map is the constant background bit for bit; a float map holding
+    texel / 255 * intensity is the RGBA8 map with that intensity bit for bit; values above 1 come through unclipped (only
+    Film::AddSample's luminance clamp at 12 applies, Film.cpp:38-43)."""
+    scene = presets.glass_mirror(48, 48)
+    a0, _ = po.Scene(scene).render(2, 6, seed=11)
+    a1, _ = po.Scene(dict(scene, skybox={"faces": np.full((6, 4, 4, 3), 0.2, np.float32)})).render(2, 6, seed=11)
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+    u8 = gradient_faces(16, seed=9)
+    f32 = (u8[..., :3].astype(np.float32) / np.float32(255)) * np.float32(1.75)
+    b0, _ = po.Scene(dict(scene, skybox={"faces": u8, "intensity": 1.75})).render(2, 6, seed=3)
+    b1, _ = po.Scene(dict(scene, skybox={"faces": f32})).render(2, 6, seed=3)
+    assert np.array_equal(b0.view(np.uint32), b1.view(np.uint32))
+    hdr = np.zeros((6, 2, 2, 3), np.float32); hdr[..., 0] = 7.5; hdr[..., 1] = 3.0; hdr[..., 2] = 40.0  # luminance 6.63: below the clamp
+    S = po.Scene(dict(empty_scene(8, 6, (0, 0, 0)), skybox={"faces": hdr}))
+    c, _ = S.render(1, 2)
+    assert np.array_equal(c, np.broadcast_to(np.float32([7.5, 3.0, 40.0]), c.shape))
+
+
 def test_cubemap_faces_and_orientation():
     faces = gradient_faces()
     for rot in [(0, 0, 0), (0, 90, 0), (0, 180, 0), (0, 270, 0), (80, 30, 0), (-80, 200, 10), (35, 45, 20)]:

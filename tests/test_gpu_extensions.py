@@ -27,6 +27,51 @@ def test_uniform_cubemap_is_the_constant_background(gpu):
     assert np.array_equal(f0.Accum().view(np.uint32), f2.Accum().view(np.uint32))
 
 
+def test_float_cubemap(gpu):
+    """ptamd_scene_set_skybox_f32: a constant 0.2 float map is the constant background bit for bit, a float map holding
+    texel / 255 * intensity is the RGBA8 map bit for bit, radiance above 1 arrives unclipped, and an RGBA8 map can
+    replace a float one and back."""
+    scene = presets.glass_mirror(64, 64)
+    pt, cam = gpu.build_scene(scene)
+    films = [gpu.Film(64, 64) for _ in range(5)]
+    gpu.Render(cam, pt, films[0], 3, 6, seed=11)
+    pt.SetSkyboxFloat(np.full((6, 4, 4, 3), 0.2, np.float32))
+    gpu.Render(cam, pt, films[1], 3, 6, seed=11)
+    assert np.array_equal(films[0].Accum().view(np.uint32), films[1].Accum().view(np.uint32))
+    u8 = gradient_faces(16, seed=9)
+    pt.SetSkybox(u8, 1.75)
+    gpu.Render(cam, pt, films[2], 3, 6, seed=11)
+    pt.SetSkyboxFloat((u8[..., :3].astype(np.float32) / np.float32(255)) * np.float32(1.75))
+    gpu.Render(cam, pt, films[3], 3, 6, seed=11)
+    assert np.array_equal(films[2].Accum().view(np.uint32), films[3].Accum().view(np.uint32))
+    assert not np.array_equal(films[0].Accum(), films[2].Accum())
+    pt.SetSkyboxFloat(None)
+    gpu.Render(cam, pt, films[4], 3, 6, seed=11)
+    assert np.array_equal(films[0].Accum().view(np.uint32), films[4].Accum().view(np.uint32))
+    hdr = np.zeros((6, 2, 2, 3), np.float32); hdr[..., 0] = 7.5; hdr[..., 1] = 3.0; hdr[..., 2] = 40.0
+    pt, cam = gpu.build_scene(dict(empty_scene(16, 8, (0, 0, 0)), skybox={"faces": hdr}))
+    f = gpu.Film(16, 8)
+    gpu.Render(cam, pt, f, 1, 2)
+    a = f.Accum()
+    assert np.array_equal(a, np.broadcast_to(np.float32([7.5, 3.0, 40.0]), a.shape))
+
+
+def test_float_cubemap_scene_same_seed(gpu):
+    """A scene lit through its open front by a float map with radiance up to 6: GPU and oracle, same random stream."""
+    rng = np.random.default_rng(12)
+    faces = (rng.random((6, 32, 32, 3)) ** 3 * 6.0).astype(np.float32)
+    scene = dict(presets.glass_mirror(96, 96), skybox={"faces": faces})
+    scene["camera"] = dict(scene["camera"], pos=(2.78, 2.73, -2.0), fov=70.0)
+    pt, cam = gpu.build_scene(scene)
+    film = gpu.Film(96, 96)
+    gpu.Render(cam, pt, film, 2, 8, seed=4)
+    a = film.Accum()
+    oa, _ = po.Scene(scene).render(2, 8, seed=4)
+    close = np.abs(a - oa).max(axis=-1) <= 2e-3 + 2e-3 * np.abs(oa).max(axis=-1)
+    assert close.mean() >= 0.95, close.mean()
+    assert abs(lum(a).mean() - lum(oa).mean()) <= 0.03 * lum(oa).mean()
+
+
 def test_cubemap_lookup_matches_oracle_exactly(gpu):
     faces = gradient_faces(32)
     for rot in [(0, 0, 0), (0, 90, 0), (0, 180, 0), (80, 30, 0), (-80, 200, 10), (35, 45, 20)]:

@@ -215,6 +215,18 @@ def test_jpeg_images_decode_to_the_reference_texels(tmp_path):
             assert "JPEG" in str(e) or "image" in str(e)
 
 
+def test_jpeg_header_that_claims_more_than_the_file_holds_is_refused():
+    """A forged frame header: a small file whose SOF claims 23170 x 23170 pixels would make the decoder allocate
+    gigabytes of component planes before reading a single coefficient. It is refused from the header alone."""
+    import os
+    from conftest import GOLDEN
+    raw = bytearray(np.load(os.path.join(GOLDEN, "jpeg_cases.npz"))["file_0"].tobytes())
+    sof = next(i for i in range(len(raw) - 1) if raw[i] == 0xFF and raw[i + 1] in (0xC0, 0xC1, 0xC2))
+    raw[sof + 5:sof + 9] = struct.pack(">HH", 23170, 23170)  # height, width
+    with pytest.raises(ptamd.PtamdError, match="larger than the file"):
+        ptamd.decode_image(bytes(raw))
+
+
 def test_mutated_model_files_never_crash_the_loader(tmp_path):
     """Byte-level mutations of the committed .glb files (flipped bytes anywhere: header, JSON, accessors' data, PNG and
     JPEG streams; truncations): every load either succeeds or raises a clean error. Runs in a child process, so a crash
