@@ -222,6 +222,7 @@ def test_jpeg_header_that_claims_more_than_the_file_holds_is_refused():
     from conftest import GOLDEN
     raw = bytearray(np.load(os.path.join(GOLDEN, "jpeg_cases.npz"))["file_0"].tobytes())
     sof = next(i for i in range(len(raw) - 1) if raw[i] == 0xFF and raw[i + 1] in (0xC0, 0xC1, 0xC2))
+    import struct
     raw[sof + 5:sof + 9] = struct.pack(">HH", 23170, 23170)  # height, width
     with pytest.raises(ptamd.PtamdError, match="larger than the file"):
         ptamd.decode_image(bytes(raw))
