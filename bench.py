@@ -236,20 +236,24 @@ def run_workload(rk, config, steps, warmup, spp_arg=None, depth_arg=None, scalin
     dict (None on other ranks). roulette overrides the configuration's Russian-roulette setting."""
     import ptamd
     import shard
-    torch = rk.torch
-    tmpdir = tempfile.mkdtemp(prefix="ptbench_")
+    tmpdir = tempfile.mkdtemp(prefix="ptbench_")  # generated model files: the GPU library and the CPU legs load them from here
     try:
-        scene, name, mode, rr, spp_default, depth_default, sky = build_config(config, tmpdir)
-        if roulette is not None:
-            rr = roulette
-        W, H = scene["film"]
-        depth = depth_arg if depth_arg is not None else depth_default
-        spp_in = spp_arg if spp_arg is not None else spp_default
-        if mode == "tile" and scaling == "weak":
-            raise SystemExit("the tile-sharded configuration has a fixed film: strong scaling only")
-        pt, cam = ptamd.build_scene(scene)
+        return _run_workload(rk, ptamd, shard, tmpdir, config, steps, warmup, spp_arg, depth_arg, scaling, want_cpu, cpu_budget, roulette, dump)
     finally:
-        shutil.rmtree(tmpdir, ignore_errors=True)  # the library keeps its own copy of the geometry
+        shutil.rmtree(tmpdir, ignore_errors=True)
+
+
+def _run_workload(rk, ptamd, shard, tmpdir, config, steps, warmup, spp_arg, depth_arg, scaling, want_cpu, cpu_budget, roulette, dump):
+    torch = rk.torch
+    scene, name, mode, rr, spp_default, depth_default, sky = build_config(config, tmpdir)
+    if roulette is not None:
+        rr = roulette
+    W, H = scene["film"]
+    depth = depth_arg if depth_arg is not None else depth_default
+    spp_in = spp_arg if spp_arg is not None else spp_default
+    if mode == "tile" and scaling == "weak":
+        raise SystemExit("the tile-sharded configuration has a fixed film: strong scaling only")
+    pt, cam = ptamd.build_scene(scene)
     if sky is not None:
         pt.SetSkyboxFloat(sky)
     stream = torch.cuda.current_stream()
