@@ -137,6 +137,52 @@ def mixed(mesh_path, w=512, h=512, mesh_pos=(2.775, 0.02, 2.8), mesh_rot=(-90.0,
     return {"film": (w, h), "camera": default_camera(), "background": (0.2, 0.2, 0.2), "objects": objs}
 
 
+def room_without_light():
+    """The six wall boxes of the reference room without its ceiling light (for scenes lit by something else)."""
+    return cornell_room_boxes()[:-1]
+
+
+def lobe_scene(kind, w=64, h=36, mesh_path=None):
+    """Small scenes that each put ONE branch of PathTracer::TraceRay's lobe choice (PathTracer.cpp:99-300) in front of the
+    camera, for converged-image comparisons with the reference:
+      rough_metal   GGX specular lobe alone (metallic 1: the diffuse weight is zero), PathTracer.cpp:213-283
+      mirror        roughness 0 specular lobe (the hL = (0,0,1) shortcut), PathTracer.cpp:218-224
+      plastic       diffuse + dielectric specular split by specProb, PathTracer.cpp:207-211, 284-300
+      half_glass    transmission 0.5, roughness 0: transmission / opaque lobes each divided by their selection
+                    probability, Fresnel split, refraction and total internal reflection, PathTracer.cpp:99-204
+      rough_glass   transmission 1, roughness 0.3: GGX interface reflection, PathTracer.cpp:122-180
+      glass_box     a transmissive Box: its hits never report a front face (Box.cpp:86-89), so eta_t = 1
+      emitter_panel a mesh whose only light is an emissive texture: radiance = e * |e| (Mesh.cpp:476-477), room light removed
+    """
+    big = {"type": "sphere", "pos": (2.78, 1.45, 2.6), "radius": 1.45}
+    side = {"type": "sphere", "pos": (4.55, 0.7, 1.5), "radius": 0.7, "mat": material(albedo=(0.2, 0.4, 0.9))}
+    objs = cornell_room_boxes()
+    if kind == "rough_metal":
+        objs += [dict(big, mat=material(albedo=(0.95, 0.7, 0.3), roughness=0.4, metallic=1.0)), side]
+    elif kind == "mirror":
+        objs += [dict(big, mat=material(albedo=(0.9, 0.95, 0.9), roughness=0.0, metallic=1.0)), side]
+    elif kind == "plastic":
+        objs += [dict(big, mat=material(albedo=(0.8, 0.25, 0.2), roughness=0.25, metallic=0.0)), side]
+    elif kind == "half_glass":
+        objs += [dict(big, mat=material(albedo=(0.9, 0.8, 0.6), roughness=0.0, ior=1.5, transmission=0.5)), side]
+    elif kind == "rough_glass":
+        objs += [dict(big, mat=material(albedo=(1, 1, 1), roughness=0.3, ior=1.45, transmission=1.0)), side]
+    elif kind == "glass_box":
+        objs += [{"type": "box", "pos": (2.5, 1.3, 2.0), "rot": (15.0, 30.0, 5.0), "size": (2.2, 2.2, 1.2),
+                  "mat": material(albedo=(1, 1, 1), roughness=0.0, ior=1.5, transmission=1.0)},
+                 dict(side, pos=(2.9, 0.9, 3.9), radius=0.9)]
+    elif kind == "emitter_panel":
+        objs = room_without_light() + [dict(big, radius=1.0, pos=(2.78, 1.0, 2.8), mat=material(albedo=(0.8, 0.8, 0.8))),
+                                       {"type": "mesh", "path": mesh_path, "pos": (2.78, 2.9, 4.9), "rot": (0.0, 0.0, 0.0), "scale": (1.0, 1.0, 1.0)}]
+    else:
+        raise ValueError(kind)
+    cam = dict(default_camera(), pos=(2.78, 2.0, -2.5))  # closer than the reference's camera: the object fills a sixth of the frame
+    return {"film": (w, h), "camera": cam, "background": (0.2, 0.2, 0.2), "objects": objs}
+
+
+LOBE_KINDS = ("rough_metal", "mirror", "plastic", "half_glass", "rough_glass", "glass_box", "emitter_panel")
+
+
 def write_scene_txt(scene, path):
     """Text form read by oracle/ref_driver.cpp. %.9g round-trips float32 exactly."""
     def fl(xs):
