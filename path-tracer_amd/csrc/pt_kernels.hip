@@ -215,6 +215,186 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
     }
 }
 
+// ---------------------------------------------------------------- sample-major render (LDS-resident scenes, many samples per launch)
+//
+// The camera has no jitter (Camera.cpp:47-48): every sample of a pixel starts with the same ray, the same closest hit and
+// the same material. render_samples_kernel therefore gives a wave a 4x4-pixel tile instead of 64 pixels: four lanes share
+// a pixel (lane & 15) and take its sample indices in turn (lane >> 4, +4, ...). Each wave finds the camera-ray hits of its 16
+// pixels once and keeps the rebuilt hit records in LDS (80 bytes per pixel); a lane whose path ends starts the next sample
+// from that record in the same trip of the bounce loop -- its next closest-hit search is already the first bounce, so one
+// search in 6.6 (mesh Cornell) or 3.6 (glass / mirror scene with roulette) is never made. (Keeping the hit per LANE in the
+// pixel-major kernel would need 17 KB of LDS per workgroup and cost a resident workgroup per CU.)
+//
+// Film: the samples of a pixel come from four lanes, so each finished sample is added to a per-pixel 64-bit fixed-point sum in
+// LDS (2^-35 steps; LDS integer atomics). Integer addition is associative: the launch's sum does not depend on which lane
+// ran which sample or in what order, and it is the exactly rounded sum of the clamped samples (Film::AddSample,
+// Film.cpp:34-46) where sequential float additions round after every sample. It is added to the film in one float
+// addition per launch, so splitting a render into launches changes the film by float rounding only (the pixel-major kernel
+// reproduces the reference's order of additions instead and is bit-identical under any split). A sample that is not finite
+// makes the pixel NaN, as a NaN added to a float sum would.
+constexpr float kFxScale = 34359738368.0f; // 2^35: |sample| <= 12 / 0.0722 < 2^8 after the luminance clamp, 2^20 samples per launch
+constexpr double kFxInv = 1.0 / 34359738368.0;
+constexpr uint32_t kSampleMajorMaxSpp = 1u << 20;
+constexpr uint32_t kSamplesAccBytes = 4 * 16 * 4 * 8;   // [wave][pixel][r, g, b, non-finite count] x u64
+constexpr uint32_t kSamplesCacheBytes = 4 * 16 * 5 * 16; // [wave][pixel][5 float4]
+PT_DEV void add_sample_fx(unsigned long long* acc, f3 c, unsigned long long times = 1ull)
+{
+    float lum = dot(c, mk3(0.2126f, 0.7152f, 0.0722f));
+    if (lum > 12.0f) c = c * (12.0f / lum);
+    const float sum = c.x + c.y + c.z;
+    if (!(fabsf(sum) < 3.0e38f)) { atomicAdd(&acc[3], 1ull); return; } // NaN or infinite
+    atomicAdd(&acc[0], (unsigned long long)__float2ll_rn(c.x * kFxScale) * times);
+    atomicAdd(&acc[1], (unsigned long long)__float2ll_rn(c.y * kFxScale) * times);
+    atomicAdd(&acc[2], (unsigned long long)__float2ll_rn(c.z * kFxScale) * times);
+}
+template <bool COUNT, bool EXT>
+__global__ __launch_bounds__(kBlock, PT_WAVES) void render_samples_kernel(DScene sc, DRenderParams rp)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    StackEntry* stack = reinterpret_cast<StackEntry*>(lds_raw);
+    const uint32_t stackBytes = (uint32_t)rp.stack_depth * kBlock * (uint32_t)sizeof(StackEntry);
+    unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds_raw + stackBytes);
+    float4* cache = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesAccBytes);
+    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesAccBytes + kSamplesCacheBytes);
+    const int slot = threadIdx.x, lane = slot & 63, wave = slot >> 6;
+    const int p = lane & 15, sub = lane >> 4;
+    unsigned long long* acc = tile_acc + (wave * 16 + p) * 4;
+    float4* rec = cache + (wave * 16 + p) * 5;
+    if (sub == 0) { acc[0] = 0ull; acc[1] = 0ull; acc[2] = 0ull; acc[3] = 0ull; }
+    const Geom geom = stage_geometry<true>(sc, lds_geom); // ends in a workgroup barrier
+    Coop coop; coop.res = nullptr; coop.mail = nullptr;   // the work-sharing traversal is not part of this kernel
+    // the workgroup covers an 8x8-pixel block, its waves the four 4x4 quadrants
+    const int bx = blockIdx.x % rp.tiles_x, by = blockIdx.x / rp.tiles_x;
+    const int px = rp.x0 + bx * 8 + (wave & 1) * 4 + (p & 3), py = rp.y0 + by * 8 + (wave >> 1) * 4 + (p >> 2);
+    const bool inside = (px < rp.x1) && (py < rp.y1);
+    const uint32_t pixel = (uint32_t)(py * rp.cam.width + px);
+    const uint32_t seed_hash = pcg_hash(rp.seed);
+    const f3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
+
+    uint32_t nrays = 0, ray_trips = 0, shade_lanes = 0, shade_trips = 0;
+    TraversalCounts tc_total; tc_total.nodes = 0; tc_total.tris = 0; tc_total.node_trips = 0; tc_total.tri_trips = 0; tc_total.steal_rounds = 0;
+    auto search = [&](const Ray& r) {
+        if (COUNT) {
+            TraversalCounts tc;
+            Best b = closest_hit<kBlock, true, false>(sc, geom, r, stack, coop, slot, &tc);
+            tc_total.nodes += tc.nodes; tc_total.tris += tc.tris; tc_total.node_trips += tc.node_trips; tc_total.tri_trips += tc.tri_trips;
+            if (wave_leader()) ++ray_trips;
+            return b;
+        }
+        return closest_hit<kBlock, false, false>(sc, geom, r, stack, coop, slot, nullptr);
+    };
+
+    // ---- the camera ray of every pixel of the tile, once (the four lanes of a pixel trace it together: coherent and cheap)
+    Ray ray = camera_ray(rp.cam, px, py);
+    bool primaryHit;
+    {
+        TraversalCounts keep = tc_total;
+        const Best best = search(ray);
+        if (COUNT && sub != 0) { tc_total = keep; } // one search per pixel in the tallies
+        primaryHit = best.obj >= 0;
+        HitInfo h;
+        h.p = mk3(0.f, 0.f, 0.f); h.n = mk3(0.f, 0.f, 1.f); h.frontFace = false; h.albedo = mk3(0.f, 0.f, 0.f); h.roughness = 1.f; h.metallic = 0.f;
+        h.emission = mk3(0.f, 0.f, 0.f); h.ior = 1.f; h.transmission = 0.f;
+        if (primaryHit) fill_hit(sc, ray, best, h);
+        if (sub == 0) {
+            rec[0] = make_float4(h.p.x, h.p.y, h.p.z, h.n.x);
+            rec[1] = make_float4(h.n.y, h.n.z, h.albedo.x, h.albedo.y);
+            rec[2] = make_float4(h.albedo.z, h.roughness, h.metallic, h.emission.x);
+            rec[3] = make_float4(h.emission.y, h.emission.z, h.ior, h.transmission);
+            rec[4] = make_float4(ray.d.x, ray.d.y, ray.d.z, h.frontFace ? 1.0f : 0.0f);
+        }
+    }
+    __syncthreads();
+
+    uint32_t s = rp.spp_begin + (uint32_t)sub;
+    const uint32_t s_end = rp.spp_begin + rp.spp_count;
+    bool active = inside && s < s_end;
+    if (!primaryHit) {
+        // the camera ray leaves the scene: every sample of the pixel is the miss radiance (PathTracer.cpp:59-60)
+        if (inside && sub == 0) {
+            add_sample_fx(acc, (EXT && sc.sky_size > 0) ? sky_lookup(sc, ray.d) : bg, (unsigned long long)rp.spp_count);
+            if (COUNT) nrays += rp.spp_count;
+        }
+        active = false;
+    }
+    const f3 camPos = ray.o;
+    float ior = 1.0f;
+    f3 T = mk3(1.f, 1.f, 1.f), L = mk3(0.f, 0.f, 0.f);
+    int bounce = 0;
+    uint32_t key = 0u;
+    bool fresh = true; // the lane's next step is the BSDF sample at its pixel's camera-ray hit: no search before it
+    while (active) {
+        bool end = false;
+        HitInfo h;
+        if (!fresh) {
+            const Best best = search(ray);
+            if (COUNT) ++nrays;
+            if (best.obj < 0) {
+                L = L + T * ((EXT && sc.sky_size > 0) ? sky_lookup(sc, ray.d) : bg); // PathTracer.cpp:59-60
+                end = true;
+            } else {
+                fill_hit(sc, ray, best, h);
+                L = L + T * h.emission;                    // PathTracer.cpp:76
+                if (bounce + 1 >= rp.depth) end = true;    // the next TraceRay would return 0 (PathTracer.cpp:35-36)
+            }
+        }
+        if (end) {
+            add_sample_fx(acc, L);
+            s += 4u;
+            if (s >= s_end) break;
+        }
+        if (fresh || end) {
+            // next sample of the pixel: the camera ray's hit comes from the tile's record
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+            h.p = mk3(q0.x, q0.y, q0.z); h.n = mk3(q0.w, q1.x, q1.y); h.albedo = mk3(q1.z, q1.w, q2.x);
+            h.roughness = q2.y; h.metallic = q2.z; h.emission = mk3(q2.w, q3.x, q3.y); h.ior = q3.z; h.transmission = q3.w;
+            h.frontFace = q4.w != 0.0f;
+            ray.o = camPos; ray.d = mk3(q4.x, q4.y, q4.z);
+            T = mk3(1.f, 1.f, 1.f); L = h.emission; ior = 1.0f; bounce = 0;
+            key = path_key(seed_hash, pixel, s);
+            fresh = false;
+            if (COUNT) ++nrays;
+        }
+        if (COUNT) { ++shade_lanes; if (wave_leader()) ++shade_trips; }
+        f3 w;
+        bool done = !sample_bsdf(h, ray, ior, w, key, (uint32_t)bounce);
+        T = T * w;
+        if (EXT && (rp.flags & kFlagRoulette) && bounce + 1 >= 3 && !done) {
+            float q = clampf(fmaxf(fmaxf(T.x, T.y), T.z), 0.05f, 1.0f);
+            if (!(rand01(key, (uint32_t)bounce, 7u) < q)) done = true;
+            else T = T * __fdiv_rn(1.0f, q);
+        }
+        ++bounce;
+        if (done) { // the path ends without a next ray: the lane reloads its pixel's record in its next trip
+            add_sample_fx(acc, L);
+            s += 4u;
+            if (s >= s_end) break;
+            fresh = true;
+        }
+    }
+    __builtin_amdgcn_wave_barrier(); // the four lanes of a pixel have left the loop; LDS runs a wave's operations in order
+    if (inside && sub == 0) {
+        const unsigned long long bad = __hip_atomic_load(&acc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        float* a = rp.accum + 3 * (size_t)pixel;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const long long v = (long long)__hip_atomic_load(&acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            a[k] = bad ? __builtin_nanf("") : a[k] + (float)((double)v * kFxInv);
+        }
+        rp.samples[pixel] += rp.spp_count;
+    }
+    if (COUNT && rp.counters) {
+        unsigned long long c[kNumCounters] = { (inside && sub == 0) ? rp.spp_count : 0u, nrays, tc_total.nodes, tc_total.tris,
+                                               ray_trips, tc_total.node_trips, tc_total.tri_trips, shade_lanes, shade_trips, 0u };
+#pragma unroll
+        for (int k = 0; k < kNumCounters; ++k) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_xor(c[k], off, 64);
+            if (lane == 0) atomicAdd(&rp.counters[k], c[k]);
+        }
+    }
+}
+
 // Camera::GetRay probe.
 __global__ void camera_rays_kernel(DCamera cam, float* out)
 {
@@ -307,6 +487,23 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const bool count = rp.counters != nullptr;
     static const bool debug = getenv("PTAMD_DEBUG") != nullptr;
     const bool ext = (rp.flags & kFlagRoulette) != 0 || sc.sky_size > 0;
+    // Many samples per pixel on an LDS-resident scene: the sample-major kernel (see render_samples_kernel). Fewer than 64
+    // samples leave its waves too short-lived; albedo-only and depth < 2 renders end at the camera ray's hit anyway.
+    static const bool noSampleMajor = getenv("PTAMD_NO_SAMPLE_MAJOR") != nullptr;
+    const size_t ldsSamples = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesAccBytes + kSamplesCacheBytes + geomBytes;
+    if (fits && !tiled && !noSampleMajor && rp.spp_count >= 64u && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only
+        && ldsSamples <= kLdsBlockBytes) {
+        const int nb = rp.tiles_x * rp.tiles_y; // one workgroup per 8x8-pixel block
+#define PT_LAUNCH_S(COUNT, EXT)                                                                                        \
+        do {                                                                                                          \
+            if (debug) fprintf(stderr, "ptamd: render_samples_kernel<%d,%d> stack %d, lds %zu B/block, %d blocks\n", (int)COUNT, (int)EXT, p.stack_depth, ldsSamples, nb); \
+            hipLaunchKernelGGL((render_samples_kernel<COUNT, EXT>), dim3(nb), dim3(kBlock), ldsSamples, stream, sc, p); \
+        } while (0)
+        if (count) { if (ext) PT_LAUNCH_S(true, true); else PT_LAUNCH_S(true, false); }
+        else { if (ext) PT_LAUNCH_S(false, true); else PT_LAUNCH_S(false, false); }
+#undef PT_LAUNCH_S
+        return hipGetLastError();
+    }
 #define PT_LAUNCH(LDSG, COUNT, EXT, TILED)                                                                                   \
     do {                                                                                                              \
         if (debug) {                                                                                                  \

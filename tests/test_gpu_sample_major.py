@@ -1,0 +1,87 @@
+"""The sample-major render kernel (launches of 64 samples per pixel and more on scenes that are traversed from LDS) against
+the pixel-major kernel, which adds a pixel's samples in the reference's order (Film::AddSample, Film.cpp:34-46, called once
+per RayTraceParallel pass, main.cpp:17-28). Both run the same paths -- the random stream is keyed by (pixel, sample) -- so
+ray counts agree and the films differ by float rounding: the sample-major kernel adds the exactly rounded sum of a
+launch's samples in one float addition, the pixel-major kernel rounds after every sample. Tolerance: 1e-5 relative (128
+sequential additions of like-signed values drift by at most 128 * 2^-24 = 8e-6) on at least 99.5 % of the pixels; the two
+kernels are separate compilations of the same source (multiply-adds may be fused differently), so on glass a last-bit
+difference in a direction now and then flips a discrete choice (an edge, total internal reflection) and one sample of a
+pixel takes another path: those pixels must still agree in the mean, and the ray totals to 1e-4."""
+import numpy as np
+import pytest
+
+from scenes import presets
+from test_extensions import empty_scene, gradient_faces
+
+pytestmark = pytest.mark.gpu
+
+
+def both(gpu, scene, spp, depth, spp_begin=0, rect=None, rr=False, seed=5):
+    """(film of one sample-major launch, film of pixel-major launches of < 64 samples each, stats of both)."""
+    pt, cam = gpu.build_scene(scene)
+    w, h = scene["film"]
+    fs, fp = gpu.Film(w, h), gpu.Film(w, h)
+    gpu.Render(cam, pt, fs, spp, depth, spp_begin=spp_begin, rect=rect, russian_roulette=rr, seed=seed, count=True)
+    ss = gpu.RenderStats()
+    rays = 0
+    b = spp_begin
+    while b < spp_begin + spp:
+        n = min(50, spp_begin + spp - b)
+        gpu.Render(cam, pt, fp, n, depth, spp_begin=b, rect=rect, russian_roulette=rr, seed=seed, count=True)
+        rays += gpu.RenderStats()["rays"]
+        b += n
+    return fs, fp, ss, rays
+
+
+def agree(a, b):
+    close = np.isclose(a, b, rtol=1e-5, atol=1e-6).all(axis=-1)
+    assert close.mean() >= 0.995, (float(close.mean()), float(np.abs(a - b).max()))
+    assert abs(float(a.mean()) - float(b.mean())) <= 2e-4 * float(b.mean()), (float(a.mean()), float(b.mean()))
+
+
+@pytest.mark.parametrize("name", ["mesh_cornell", "sphere_cornell", "glass_mirror", "box_cornell"])
+def test_sample_major_equals_pixel_major(gpu, name):
+    scene = {"mesh_cornell": lambda: presets.mesh_cornell("tests/golden/cornell_mesh.glb", 100, 54),
+             "sphere_cornell": lambda: presets.sphere_cornell(90, 70), "glass_mirror": lambda: presets.glass_mirror(64, 61),
+             "box_cornell": lambda: presets.box_cornell(72, 40)}[name]()
+    assert gpu.build_scene(scene)[0].Info()["lds_resident"] == 1
+    depth = 12 if name == "glass_mirror" else 8
+    fs, fp, ss, rays = both(gpu, scene, 130, depth, spp_begin=7)
+    a, b = fs.Accum(), fp.Accum()
+    assert np.array_equal(fs.Samples(), fp.Samples()) and int(fs.Samples().min()) == 130
+    agree(a, b)
+    assert float(b.mean()) > 1.0  # 130 samples of a lit room
+    w, h = scene["film"]
+    assert ss["samples"] == w * h * 130 and abs(ss["rays"] - rays) <= 1e-4 * rays, (ss["rays"], rays)
+    # deterministic: a second launch gives the same bits
+    pt, cam = gpu.build_scene(scene)
+    f2 = gpu.Film(w, h)
+    gpu.Render(cam, pt, f2, 130, depth, spp_begin=7, seed=5)
+    assert np.array_equal(a.view(np.uint32), f2.Accum().view(np.uint32))
+
+
+def test_sample_major_rect_roulette_and_sky(gpu):
+    """A ragged rectangle, Russian roulette and a sky map behind the open front (camera rays that leave the scene take the
+    whole-pixel shortcut of the kernel), sample ranges that add up over launches."""
+    scene = dict(presets.glass_mirror(80, 60), skybox={"faces": gradient_faces(32, seed=3), "intensity": 1.3})
+    scene["camera"] = dict(scene["camera"], pos=(2.78, 2.73, -14.0), fov=80.0)  # far outside: most camera rays miss the room
+    fs, fp, ss, rays = both(gpu, scene, 96, 20, spp_begin=0, rect=(3, 5, 77, 58), rr=True)
+    a, b = fs.Accum(), fp.Accum()
+    assert np.array_equal(fs.Samples(), fp.Samples())
+    assert (fs.Samples()[5:58, 3:77] == 96).all() and fs.Samples().sum() == 96 * 74 * 53
+    agree(a, b)
+    assert abs(ss["rays"] - rays) <= 1e-4 * rays, (ss["rays"], rays)
+    # two launches of 64 + 64 samples against one of 128: float rounding of one addition apart
+    pt, cam = gpu.build_scene(scene)
+    f1, f2 = gpu.Film(80, 60), gpu.Film(80, 60)
+    gpu.Render(cam, pt, f1, 128, 20, russian_roulette=True)
+    gpu.Render(cam, pt, f2, 64, 20, russian_roulette=True)
+    gpu.Render(cam, pt, f2, 64, 20, spp_begin=64, russian_roulette=True)
+    assert np.allclose(f1.Accum(), f2.Accum(), rtol=3e-7, atol=1e-7)  # the same kernel: the same paths
+    # an empty scene: every pixel is the sky texel, 70 times
+    sky = dict(empty_scene(40, 24, (10, 30, 0)), skybox={"faces": gradient_faces(16, seed=1), "intensity": 1.0})
+    pt, cam = gpu.build_scene(sky)
+    f70, f1 = gpu.Film(40, 24), gpu.Film(40, 24)
+    gpu.Render(cam, pt, f70, 70, 4)
+    gpu.Render(cam, pt, f1, 1, 4)
+    assert np.allclose(f70.Accum(), 70.0 * f1.Accum(), rtol=2e-7)
