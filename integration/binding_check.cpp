@@ -1,6 +1,6 @@
 // Build-container check of integration/GpuBackend.cpp (`make -C oracle binding`): builds the reference's own scene
 // objects (the literals of main.cpp:60-63, 229-305 in miniature), pushes them through the binding, and checks what can
-// be checked on the host. With a GPU it also renders four frames; without one it expects the library's "no device" error.
+// be checked on the host. With a GPU it also renders 24 frames; without one it expects the library's "no device" error.
 // Links the reference's objects and libptamd.so; test infrastructure only.
 #include <cstdio>
 #include <cstring>
@@ -46,12 +46,12 @@ int main(int argc, char** argv)
         gpu.Upload(tracer);
         EXPECT(haveGpu);
         std::vector<uint8_t> rgba;
-        for (int f = 0; f < 4; ++f) gpu.RenderFrame(camera, 5, false, true, true, rgba);
-        EXPECT(gpu.Frames() == 4 && rgba.size() == (size_t)W * H * 4);
+        for (int f = 0; f < 24; ++f) gpu.RenderFrame(camera, 5, false, true, true, rgba);
+        EXPECT(gpu.Frames() == 24 && rgba.size() == (size_t)W * H * 4);
         size_t lit = 0;
         for (size_t p = 0; p < (size_t)W * H; ++p) lit += (rgba[4 * p] | rgba[4 * p + 1] | rgba[4 * p + 2]) != 0;
         EXPECT(lit > (size_t)W * H / 4);
-        std::printf("rendered 4 frames on the GPU, %zu of %d pixels lit\n", lit, W * H);
+        std::printf("rendered 24 frames on the GPU, %zu of %d pixels lit\n", lit, W * H);
     } catch (const std::exception& e) {
         EXPECT(!haveGpu); // without a device the commit reports it; the three objects were described before that
         std::printf("no GPU here: %s\n", e.what());

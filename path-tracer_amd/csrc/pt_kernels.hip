@@ -59,6 +59,9 @@ constexpr int kNumCounters = 10;        // fields of ptamd_stats, in order
 #ifndef PT_WAVES
 #define PT_WAVES 5
 #endif
+#ifndef PT_WAVES_SM
+#define PT_WAVES_SM PT_WAVES
+#endif
 #ifndef PT_WAVES_COOP
 #define PT_WAVES_COOP 4 // the cooperative traversal needs ~112 VGPRs; spilling them costs more than the fifth wave brings
 #endif
@@ -215,59 +218,81 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
     }
 }
 
-// ---------------------------------------------------------------- sample-major render (LDS-resident scenes, many samples per launch)
+// ---------------------------------------------------------------- sample-major render (LDS-resident meshes, many samples per launch)
 //
 // The camera has no jitter (Camera.cpp:47-48): every sample of a pixel starts with the same ray, the same closest hit and
-// the same material. render_samples_kernel therefore gives a wave a 4x4-pixel tile instead of 64 pixels: four lanes share
-// a pixel (lane & 15) and take its sample indices in turn (lane >> 4, +4, ...). Each wave finds the camera-ray hits of its 16
-// pixels once and keeps the rebuilt hit records in LDS (80 bytes per pixel); a lane whose path ends starts the next sample
-// from that record in the same trip of the bounce loop -- its next closest-hit search is already the first bounce, so one
-// search in 6.6 (mesh Cornell) or 3.6 (glass / mirror scene with roulette) is never made. (Keeping the hit per LANE in the
-// pixel-major kernel would need 17 KB of LDS per workgroup and cost a resident workgroup per CU.)
+// the same material. render_samples_kernel therefore gives a wave a 4x4-pixel tile instead of 64 pixels. The wave finds the
+// camera-ray hits of its 16 pixels once and keeps the rebuilt hit records in LDS (80 bytes per pixel). Its lanes then draw
+// (pixel, sample) tickets from a counter of the tile, samples in ascending order, and a lane whose path ends starts its next
+// ticket from the pixel's record in the same trip of the bounce loop: its next closest-hit search is already the first
+// bounce, so one search in 6.6 (mesh Cornell) is never made, and no lane waits for another's longer run of samples.
+// (Keeping the hit per LANE in the pixel-major kernel would need 17 KB of LDS per workgroup and cost a resident workgroup.)
 //
-// Film: the samples of a pixel come from four lanes, so each finished sample is added to a per-pixel 64-bit fixed-point sum in
-// LDS (2^-35 steps; LDS integer atomics). Integer addition is associative: the launch's sum does not depend on which lane
-// ran which sample or in what order, and it is the exactly rounded sum of the clamped samples (Film::AddSample,
-// Film.cpp:34-46) where sequential float additions round after every sample. It is added to the film in one float
-// addition per launch, so splitting a render into launches changes the film by float rounding only (the pixel-major kernel
-// reproduces the reference's order of additions instead and is bit-identical under any split). A sample that is not finite
-// makes the pixel NaN, as a NaN added to a float sum would.
+// Film: the samples of a pixel come from many lanes, so each finished sample is added to a per-pixel 64-bit fixed-point sum
+// in LDS (2^-35 steps; LDS integer atomics). Integer addition is associative: the launch's sum does not depend on which
+// lane ran which sample or in what order (the random stream is keyed by pixel and sample, not by lane), and it is the
+// exactly rounded sum of the clamped samples (Film::AddSample, Film.cpp:34-46) where sequential float additions round after
+// every sample. It is added to the film in one float addition per launch, so splitting a render into launches changes
+// the film by float rounding only (the pixel-major kernel reproduces the reference's order of additions instead and is
+// bit-identical under any split). A sample that is not finite makes the pixel NaN, as it would in a float sum.
 constexpr float kFxScale = 34359738368.0f; // 2^35: |sample| <= 12 / 0.0722 < 2^8 after the luminance clamp, 2^20 samples per launch
 constexpr double kFxInv = 1.0 / 34359738368.0;
 constexpr uint32_t kSampleMajorMaxSpp = 1u << 20;
-constexpr uint32_t kSamplesAccBytes = 4 * 16 * 4 * 8;   // [wave][pixel][r, g, b, non-finite count] x u64
+struct SampleTile {                  // per wave, in LDS
+    unsigned long long acc[16][4];   // r, g, b sums and the count of non-finite samples of each pixel
+    uint32_t list[16];               // the pixels (0..15) that are path traced: inside the rectangle, camera ray hits something
+    uint32_t next;                   // ticket counter of the tile
+    uint32_t pad[3];
+};
+static_assert(sizeof(SampleTile) % 16 == 0, "the hit records behind the tiles are read 16 bytes at a time");
+constexpr uint32_t kSamplesTileBytes = 4 * sizeof(SampleTile);
 constexpr uint32_t kSamplesCacheBytes = 4 * 16 * 5 * 16; // [wave][pixel][5 float4]
+PT_DEV unsigned long long to_fixed(float c)
+{
+    if (c < 0.0f) return (unsigned long long)__float2ll_rn(c * kFxScale); // not a radiance this renderer produces; kept exact anyway
+    // c * 2^35 < 2^43 in two conversions that each fit 32 bits: the upper 19 bits from c * 2^11, the lower 24 from its fraction
+    const float hiF = c * 2048.0f;
+    const uint32_t hi = (uint32_t)hiF;
+    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fractf(hiF) * 16777216.0f);
+    return ((unsigned long long)hi << 24) + lo;
+}
 PT_DEV void add_sample_fx(unsigned long long* acc, f3 c, unsigned long long times = 1ull)
 {
     float lum = dot(c, mk3(0.2126f, 0.7152f, 0.0722f));
     if (lum > 12.0f) c = c * (12.0f / lum);
-    const float sum = c.x + c.y + c.z;
-    if (!(fabsf(sum) < 3.0e38f)) { atomicAdd(&acc[3], 1ull); return; } // NaN or infinite
-    atomicAdd(&acc[0], (unsigned long long)__float2ll_rn(c.x * kFxScale) * times);
-    atomicAdd(&acc[1], (unsigned long long)__float2ll_rn(c.y * kFxScale) * times);
-    atomicAdd(&acc[2], (unsigned long long)__float2ll_rn(c.z * kFxScale) * times);
+    const float sum = fabsf(c.x) + fabsf(c.y) + fabsf(c.z);
+    if (!(sum < 768.0f)) { // NaN, infinite, or a magnitude that the clamp of non-negative radiance cannot leave
+        if (!(sum < 3.0e38f)) { atomicAdd(&acc[3], 1ull); return; }
+        atomicAdd(&acc[0], (unsigned long long)__float2ll_rn(c.x * kFxScale) * times);
+        atomicAdd(&acc[1], (unsigned long long)__float2ll_rn(c.y * kFxScale) * times);
+        atomicAdd(&acc[2], (unsigned long long)__float2ll_rn(c.z * kFxScale) * times);
+        return;
+    }
+    atomicAdd(&acc[0], to_fixed(c.x) * times);
+    atomicAdd(&acc[1], to_fixed(c.y) * times);
+    atomicAdd(&acc[2], to_fixed(c.z) * times);
 }
 template <bool COUNT, bool EXT>
-__global__ __launch_bounds__(kBlock, PT_WAVES) void render_samples_kernel(DScene sc, DRenderParams rp)
+__global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DScene sc, DRenderParams rp)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     StackEntry* stack = reinterpret_cast<StackEntry*>(lds_raw);
     const uint32_t stackBytes = (uint32_t)rp.stack_depth * kBlock * (uint32_t)sizeof(StackEntry);
-    unsigned long long* tile_acc = reinterpret_cast<unsigned long long*>(lds_raw + stackBytes);
-    float4* cache = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesAccBytes);
-    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesAccBytes + kSamplesCacheBytes);
-    const int slot = threadIdx.x, lane = slot & 63, wave = slot >> 6;
-    const int p = lane & 15, sub = lane >> 4;
-    unsigned long long* acc = tile_acc + (wave * 16 + p) * 4;
-    float4* rec = cache + (wave * 16 + p) * 5;
-    if (sub == 0) { acc[0] = 0ull; acc[1] = 0ull; acc[2] = 0ull; acc[3] = 0ull; }
+    const int slot = threadIdx.x, lane = slot & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(slot >> 6); // wave-uniform by construction: tile addresses and origins stay in scalar registers
+    SampleTile& tile = reinterpret_cast<SampleTile*>(lds_raw + stackBytes)[wave];
+    float4* cache = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes) + wave * (16 * 5);
+    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes);
+    const int p0 = lane & 15; // the pixel this lane traces the camera ray of, with three others
+    const bool first = lane < 16;
+    if (lane == 0) tile.next = 0u;
+    if (first) { tile.acc[p0][0] = 0ull; tile.acc[p0][1] = 0ull; tile.acc[p0][2] = 0ull; tile.acc[p0][3] = 0ull; }
     const Geom geom = stage_geometry<true>(sc, lds_geom); // ends in a workgroup barrier
     Coop coop; coop.res = nullptr; coop.mail = nullptr;   // the work-sharing traversal is not part of this kernel
     // the workgroup covers an 8x8-pixel block, its waves the four 4x4 quadrants
     const int bx = blockIdx.x % rp.tiles_x, by = blockIdx.x / rp.tiles_x;
-    const int px = rp.x0 + bx * 8 + (wave & 1) * 4 + (p & 3), py = rp.y0 + by * 8 + (wave >> 1) * 4 + (p >> 2);
-    const bool inside = (px < rp.x1) && (py < rp.y1);
-    const uint32_t pixel = (uint32_t)(py * rp.cam.width + px);
+    const int tx0 = rp.x0 + bx * 8 + (wave & 1) * 4, ty0 = rp.y0 + by * 8 + (wave >> 1) * 4;
+    const int W = rp.cam.width;
     const uint32_t seed_hash = pcg_hash(rp.seed);
     const f3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
 
@@ -284,46 +309,58 @@ __global__ __launch_bounds__(kBlock, PT_WAVES) void render_samples_kernel(DScene
         return closest_hit<kBlock, false, false>(sc, geom, r, stack, coop, slot, nullptr);
     };
 
-    // ---- the camera ray of every pixel of the tile, once (the four lanes of a pixel trace it together: coherent and cheap)
-    Ray ray = camera_ray(rp.cam, px, py);
-    bool primaryHit;
+    // ---- the camera ray of every pixel of the tile, once (four lanes trace each: coherent, and once per launch)
+    f3 camPos;
+    uint32_t nvalid;
     {
-        TraversalCounts keep = tc_total;
+        const int px = tx0 + (p0 & 3), py = ty0 + (p0 >> 2);
+        const bool inside = (px < rp.x1) && (py < rp.y1);
+        const Ray ray = camera_ray(rp.cam, px, py);
+        camPos = ray.o;
+        const TraversalCounts keep = tc_total;
         const Best best = search(ray);
-        if (COUNT && sub != 0) { tc_total = keep; } // one search per pixel in the tallies
-        primaryHit = best.obj >= 0;
+        if (COUNT && !first) tc_total = keep; // one search per pixel in the tallies
+        const bool primaryHit = best.obj >= 0;
         HitInfo h;
         h.p = mk3(0.f, 0.f, 0.f); h.n = mk3(0.f, 0.f, 1.f); h.frontFace = false; h.albedo = mk3(0.f, 0.f, 0.f); h.roughness = 1.f; h.metallic = 0.f;
         h.emission = mk3(0.f, 0.f, 0.f); h.ior = 1.f; h.transmission = 0.f;
         if (primaryHit) fill_hit(sc, ray, best, h);
-        if (sub == 0) {
+        const bool valid = inside && primaryHit;
+        const unsigned long long validMask = __ballot(valid) & 0xffffull;
+        nvalid = (uint32_t)__popcll(validMask);
+        if (first) {
+            float4* rec = cache + p0 * 5;
             rec[0] = make_float4(h.p.x, h.p.y, h.p.z, h.n.x);
             rec[1] = make_float4(h.n.y, h.n.z, h.albedo.x, h.albedo.y);
             rec[2] = make_float4(h.albedo.z, h.roughness, h.metallic, h.emission.x);
             rec[3] = make_float4(h.emission.y, h.emission.z, h.ior, h.transmission);
             rec[4] = make_float4(ray.d.x, ray.d.y, ray.d.z, h.frontFace ? 1.0f : 0.0f);
+            if (valid) tile.list[rank_in(validMask)] = (uint32_t)p0;
+            if (inside && !primaryHit) {
+                // the camera ray leaves the scene: every sample of the pixel is the miss radiance (PathTracer.cpp:59-60)
+                add_sample_fx(tile.acc[p0], (EXT && sc.sky_size > 0) ? sky_lookup(sc, ray.d) : bg, (unsigned long long)rp.spp_count);
+                if (COUNT) nrays += rp.spp_count;
+            }
         }
     }
     __syncthreads();
 
-    uint32_t s = rp.spp_begin + (uint32_t)sub;
-    const uint32_t s_end = rp.spp_begin + rp.spp_count;
-    bool active = inside && s < s_end;
-    if (!primaryHit) {
-        // the camera ray leaves the scene: every sample of the pixel is the miss radiance (PathTracer.cpp:59-60)
-        if (inside && sub == 0) {
-            add_sample_fx(acc, (EXT && sc.sky_size > 0) ? sky_lookup(sc, ray.d) : bg, (unsigned long long)rp.spp_count);
-            if (COUNT) nrays += rp.spp_count;
-        }
-        active = false;
-    }
-    const f3 camPos = ray.o;
+    // tickets: t -> sample t / nvalid of the (t % nvalid)-th traced pixel; t < 16 * 2^20, so the multiply-high by
+    // ceil(2^32 / nvalid) divides exactly. The counter is an LDS word of the tile (a returning LDS atomic). Measured on the
+    // mesh Cornell at 1024 / 128 samples and the glass / mirror scene at 256 / 64, in Msamples/s: this form 4181 / 4117 /
+    // 10709 / 9670; a wave-uniform counter with ballot + mbcnt ranking 4177 / 4112 / 9778 / 8811 (it costs the roulette
+    // build 30 spilled registers); fixed shares per lane 4019 / 3840 / 9434 / 8016 (lanes wait for the longest share);
+    // the pixel-major kernel 3900 / 3746 / 10304 / 9562.
+    const uint32_t total = nvalid * rp.spp_count;
+    const uint32_t magic = nvalid > 1u ? 0xFFFFFFFFu / nvalid + 1u : 0u;
     float ior = 1.0f;
     f3 T = mk3(1.f, 1.f, 1.f), L = mk3(0.f, 0.f, 0.f);
     int bounce = 0;
     uint32_t key = 0u;
-    bool fresh = true; // the lane's next step is the BSDF sample at its pixel's camera-ray hit: no search before it
-    while (active) {
+    Ray ray; ray.o = camPos; ray.d = mk3(0.f, 0.f, 1.f);
+    uint32_t pi = 0u;  // the pixel (0..15) of the lane's current sample
+    bool fresh = true; // the lane's next step is the BSDF sample at a camera-ray hit from the tile's records: no search before it
+    for (;;) {
         bool end = false;
         HitInfo h;
         if (!fresh) {
@@ -337,21 +374,24 @@ __global__ __launch_bounds__(kBlock, PT_WAVES) void render_samples_kernel(DScene
                 L = L + T * h.emission;                    // PathTracer.cpp:76
                 if (bounce + 1 >= rp.depth) end = true;    // the next TraceRay would return 0 (PathTracer.cpp:35-36)
             }
-        }
-        if (end) {
-            add_sample_fx(acc, L);
-            s += 4u;
-            if (s >= s_end) break;
+            if (end) add_sample_fx(tile.acc[pi], L);
         }
         if (fresh || end) {
-            // next sample of the pixel: the camera ray's hit comes from the tile's record
+            const uint32_t t = atomicAdd(&tile.next, 1u);
+            if (t >= total) break;
+            uint32_t q;
+            if (nvalid == 16u) { q = t >> 4; pi = t & 15u; }
+            else { q = nvalid > 1u ? __umulhi(t, magic) : t; pi = tile.list[t - q * nvalid]; }
+            const uint32_t pixel = (uint32_t)((ty0 + (int)(pi >> 2)) * W + tx0 + (int)(pi & 3u));
+            key = path_key(seed_hash, pixel, rp.spp_begin + q);
+            // the camera ray's hit comes from the tile's record
+            const float4* rec = cache + pi * 5u;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
             h.p = mk3(q0.x, q0.y, q0.z); h.n = mk3(q0.w, q1.x, q1.y); h.albedo = mk3(q1.z, q1.w, q2.x);
             h.roughness = q2.y; h.metallic = q2.z; h.emission = mk3(q2.w, q3.x, q3.y); h.ior = q3.z; h.transmission = q3.w;
             h.frontFace = q4.w != 0.0f;
             ray.o = camPos; ray.d = mk3(q4.x, q4.y, q4.z);
             T = mk3(1.f, 1.f, 1.f); L = h.emission; ior = 1.0f; bounce = 0;
-            key = path_key(seed_hash, pixel, s);
             fresh = false;
             if (COUNT) ++nrays;
         }
@@ -365,32 +405,34 @@ __global__ __launch_bounds__(kBlock, PT_WAVES) void render_samples_kernel(DScene
             else T = T * __fdiv_rn(1.0f, q);
         }
         ++bounce;
-        if (done) { // the path ends without a next ray: the lane reloads its pixel's record in its next trip
-            add_sample_fx(acc, L);
-            s += 4u;
-            if (s >= s_end) break;
+        if (done) { // the path ends without a next ray: the lane draws its next ticket in its next trip
+            add_sample_fx(tile.acc[pi], L);
             fresh = true;
         }
     }
-    __builtin_amdgcn_wave_barrier(); // the four lanes of a pixel have left the loop; LDS runs a wave's operations in order
-    if (inside && sub == 0) {
-        const unsigned long long bad = __hip_atomic_load(&acc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        float* a = rp.accum + 3 * (size_t)pixel;
+    __builtin_amdgcn_wave_barrier(); // every lane has left the loop; LDS runs a wave's operations in order
+    {
+        const int px = tx0 + (p0 & 3), py = ty0 + (p0 >> 2);
+        if (first && px < rp.x1 && py < rp.y1) {
+            const uint32_t pixel = (uint32_t)(py * W + px);
+            const unsigned long long bad = __hip_atomic_load(&tile.acc[p0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            float* a = rp.accum + 3 * (size_t)pixel;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const long long v = (long long)__hip_atomic_load(&acc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            a[k] = bad ? __builtin_nanf("") : a[k] + (float)((double)v * kFxInv);
+            for (int k = 0; k < 3; ++k) {
+                const long long v = (long long)__hip_atomic_load(&tile.acc[p0][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                a[k] = bad ? __builtin_nanf("") : a[k] + (float)((double)v * kFxInv);
+            }
+            rp.samples[pixel] += rp.spp_count;
         }
-        rp.samples[pixel] += rp.spp_count;
-    }
-    if (COUNT && rp.counters) {
-        unsigned long long c[kNumCounters] = { (inside && sub == 0) ? rp.spp_count : 0u, nrays, tc_total.nodes, tc_total.tris,
-                                               ray_trips, tc_total.node_trips, tc_total.tri_trips, shade_lanes, shade_trips, 0u };
+        if (COUNT && rp.counters) {
+            unsigned long long c[kNumCounters] = { (first && px < rp.x1 && py < rp.y1) ? rp.spp_count : 0u, nrays, tc_total.nodes, tc_total.tris,
+                                                   ray_trips, tc_total.node_trips, tc_total.tri_trips, shade_lanes, shade_trips, 0u };
 #pragma unroll
-        for (int k = 0; k < kNumCounters; ++k) {
+            for (int k = 0; k < kNumCounters; ++k) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_xor(c[k], off, 64);
-            if (lane == 0) atomicAdd(&rp.counters[k], c[k]);
+                for (int off = 32; off > 0; off >>= 1) c[k] += __shfl_xor(c[k], off, 64);
+                if (lane == 0) atomicAdd(&rp.counters[k], c[k]);
+            }
         }
     }
 }
@@ -487,10 +529,11 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const bool count = rp.counters != nullptr;
     static const bool debug = getenv("PTAMD_DEBUG") != nullptr;
     const bool ext = (rp.flags & kFlagRoulette) != 0 || sc.sky_size > 0;
-    // Many samples per pixel on an LDS-resident scene: the sample-major kernel (see render_samples_kernel). Fewer than 64
-    // samples leave its waves too short-lived; albedo-only and depth < 2 renders end at the camera ray's hit anyway.
-    static const bool noSampleMajor = getenv("PTAMD_NO_SAMPLE_MAJOR") != nullptr;
-    const size_t ldsSamples = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesAccBytes + kSamplesCacheBytes + geomBytes;
+    // Many samples per pixel on a scene that is traversed from LDS: the sample-major kernel (see render_samples_kernel).
+    // Fewer than 64 samples leave its waves too short-lived; albedo-only and depth < 2 renders end at the camera ray's hit
+    // anyway. PTAMD_NO_SAMPLE_MAJOR=1 (read per launch) keeps every launch on the pixel-major kernel.
+    const bool noSampleMajor = getenv("PTAMD_NO_SAMPLE_MAJOR") != nullptr;
+    const size_t ldsSamples = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + geomBytes;
     if (fits && !tiled && !noSampleMajor && rp.spp_count >= 64u && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only
         && ldsSamples <= kLdsBlockBytes) {
         const int nb = rp.tiles_x * rp.tiles_y; // one workgroup per 8x8-pixel block

@@ -142,7 +142,8 @@ def test_config2_full_size_properties(gpu, golden):
     f2 = gpu.Film(w, h)
     gpu.Render(cam, pt, f2, 100, 8, spp_begin=0)
     gpu.Render(cam, pt, f2, spp - 100, 8, spp_begin=100)
-    assert np.array_equal(f2.Accum()[::7].view(np.uint32), film.Accum()[::7].view(np.uint32))
+    # launches of 64 samples and more on this scene sum their samples exactly and add the sum once: a split moves float rounding
+    assert np.allclose(f2.Accum()[::7], film.Accum()[::7], rtol=3e-7, atol=1e-7)
 
 
 def test_quad_primitives_match_separate_triangles(gpu, monkeypatch):

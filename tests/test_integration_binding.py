@@ -26,4 +26,4 @@ def test_binding_compiles_against_the_reference_and_behaves_on_the_host():
 def test_binding_renders_frames_on_the_gpu(gpu):
     out = subprocess.run([CHECK, "tests/golden/cornell_mesh.glb"], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rendered 4 frames on the GPU" in out.stdout and "0 failure(s)" in out.stdout
+    assert "rendered 24 frames on the GPU" in out.stdout and "0 failure(s)" in out.stdout
