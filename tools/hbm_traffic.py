@@ -14,7 +14,7 @@ def first_dispatch(d, counter):
     per = {}
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "render_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if ("render_kernel" in r["Kernel_Name"] or "render_samples_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
                 k = int(r["Dispatch_Id"])
                 per.setdefault(k, [r["Kernel_Name"], 0.0])
                 per[k][1] += float(r["Counter_Value"])
@@ -28,13 +28,18 @@ _, write_kb = first_dispatch(out + "/write", "WRITE_SIZE")
 import re
 m = re.search(r"(\d+) spp", bench["config"]["workload"])
 d = re.search(r"(\d+) bounces", bench["config"]["workload"])
+# FETCH_SIZE tallies every memory-side read request at 64 bytes. Wide coalesced reads (the film) go out as 128-byte
+# requests, so their bytes are twice the reported figure; the 16-byte gathers of a walk through a big mesh go out as 64-byte
+# requests and are reported exactly (profiles/r3_fetch_calibration.json: tools/ubench/fetch_calib.hip, known byte counts).
+factor = 1.0 if cfg == 3 else 2.0
 print(json.dumps({
     "kernel": name.split("(")[0], "config": cfg, "workload": bench["config"]["workload"],
     "spp": int(m.group(1)), "depth": int(d.group(1)),
-    "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
-    "bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+    "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "fetch_factor": factor,
+    "bytes_per_launch": factor * fetch_kb * 1024 + write_kb * 1024,
     "bytes_per_launch_fetch_as_reported": fetch_kb * 1024 + write_kb * 1024,
     "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate runs of `python3 bench.py --config %d --no-cpu --steps 1 "
-           "--warmup 0` (tools/profile_bench.sh), first render_kernel dispatch of each; bytes = 2 * FETCH_SIZE_KB * 1024 (gfx950 reports "
-           "half the bytes of wide coalesced reads; for the 16-byte gathers of a big mesh that factor is uncalibrated, so the as-reported "
-           "sum is given too) + WRITE_SIZE_KB * 1024" % cfg}, indent=1))
+           "--warmup 0` (tools/profile_bench.sh), first render kernel dispatch of each; bytes = fetch_factor * FETCH_SIZE_KB * 1024 + "
+           "WRITE_SIZE_KB * 1024. fetch_factor: 2 where the film's coalesced reads dominate (128-byte requests tallied at 64), 1 for "
+           "configuration 3, whose reads are 16-byte gathers that leave L2 as 64-byte requests (profiles/r3_fetch_calibration.json: "
+           "64-byte records read by four 16-byte loads per lane report 0.95-1.00 of their bytes)" % cfg}, indent=1))
