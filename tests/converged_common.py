@@ -4,15 +4,19 @@ reference's sources), the standard error of that mean from the spread of its eig
 the camera ray meets, and each material region's mean luminance in every run.
 
 What is compared, and why these numbers:
-  * per pixel: |image - reference mean| <= 4 sigma on at least 99 % of the pixels, sigma^2 = stderr^2 * (1 + reference
-    samples / own samples) (the image under test has its own noise, scaled from the reference's by the sample counts),
-    with a floor of 2e-4 of the pixel's value + 1e-5 for pixels without noise (a directly seen light). With eight runs the
-    standard error has seven degrees of freedom: a correct renderer leaves about 0.5 % of the pixels outside 4 sigma.
+  * per pixel: |image - reference mean| <= 4 sigma on at least 98 % of the pixels and <= 5 sigma on at least 99 %,
+    sigma^2 = stderr^2 * (1 + reference samples / own samples) (the image under test has its own noise, scaled from the
+    reference's by the sample counts), with a floor of 2e-4 of the pixel's value + 1e-5 for pixels without noise (a directly
+    seen light). The standard error comes from eight runs (seven degrees of freedom) of samples with a heavy, clamped tail
+    (Film.cpp:38-43), so it is itself uncertain: two independent correct estimates leave 0.5-1.6 % of the pixels outside
+    4 sigma and under 0.5 % outside 5 sigma (measured: the restatement against these fixtures, and the fixtures' runs
+    against each other).
   * per material region (the pixels whose camera ray meets one material; at least 24 pixels): mean luminance within
-    0.5 % of the reference's, or within 4 sigma of the region mean where the reference's own run-to-run spread is larger
-    than that (small or dim regions).
-A bias in one lobe's weight (PathTracer.cpp:99-300) moves the region of the object that isolates the lobe by far more than
-0.5 %: a 10 % error in the specular weight of the rough-metal sphere moves its region by about 10 %."""
+    0.5 % of the reference's, or within 4 sigma of the region mean where the run-to-run spread of the two estimates is
+    larger than that (small or dim regions, or few own samples); the same for the whole image.
+The lobe scenes are lit by a ceiling-wide panel, so their region means are known to 0.1-0.3 % from the reference's 32 768
+samples per pixel. A bias in one lobe's weight (PathTracer.cpp:99-300) moves the region of the object that isolates the
+lobe by about as much: a 10 % error in the specular weight of the rough-metal sphere moves its region by about 10 %."""
 import os
 import sys
 
@@ -42,30 +46,33 @@ def scene_of(name, tmpdir):
     return scene, depth
 
 
-def check(name, image, own_spp, g, min_fraction=0.99):
-    """image: (H, W, 3) clamped-mean radiance at own_spp samples per pixel. Returns a short report; raises on disagreement."""
+def check(name, image, own_spp, g):
+    """image: (H, W, 3) clamped-mean radiance at own_spp samples per pixel. Returns (fraction of pixels within 4 sigma,
+    region report); raises on disagreement."""
     mean, stderr, region = g["mean"].astype(np.float64), g["stderr"].astype(np.float64), g["region"]
     ref_spp = float(g["spp"]) * float(g["chunks"])
     image = image.astype(np.float64)
     sigma = np.sqrt(stderr ** 2 * (1.0 + ref_spp / float(own_spp)))
-    tol = 4.0 * sigma + 2e-4 * np.abs(mean) + 1e-5
-    ok = (np.abs(image - mean) <= tol).all(axis=-1)
-    assert ok.mean() >= min_fraction, "%s: %.2f %% of the pixels within 4 sigma of the reference" % (name, 100 * ok.mean())
+    floor = 2e-4 * np.abs(mean) + 1e-5
+    dev = np.abs(image - mean)
+    in4, in5 = (dev <= 4.0 * sigma + floor).all(axis=-1).mean(), (dev <= 5.0 * sigma + floor).all(axis=-1).mean()
+    assert in4 >= 0.98 and in5 >= 0.99, "%s: %.2f %% of the pixels within 4 sigma of the reference, %.2f %% within 5" % (name, 100 * in4, 100 * in5)
     lum = (image * LUM).sum(-1)
-    chunks = g["region_lum"].astype(np.float64)  # (regions, runs)
+    chunks = g["region_lum"].astype(np.float64)  # (regions, runs); region 0 = camera rays that miss
+    runs = chunks.shape[1]
+    own = float(g["spp"]) / float(own_spp)       # variance of the image under test in units of one run's
+
+    def compare(what, got, per_run):
+        ref, s_run = per_run.mean(), per_run.std(ddof=1)
+        allowed = max(0.005 * abs(ref), 4.0 * s_run * np.sqrt(1.0 / runs + own))
+        assert abs(got - ref) <= allowed, "%s %s: mean luminance %.5f against the reference's %.5f (%+.2f %%, allowed %.2f %%)" % (
+            name, what, got, ref, 100 * (got - ref) / ref, 100 * allowed / abs(ref))
+        return ref, got, (got - ref) / ref, allowed / abs(ref)
+
     report = []
+    sizes = np.array([(region == r).sum() for r in range(chunks.shape[0])], np.float64)
     for r in range(1, chunks.shape[0]):
-        m = region == r
-        if m.sum() < 24:
-            continue
-        ref = chunks[r].mean()
-        s_run = chunks[r].std(ddof=1)                       # spread of one run's region mean (spp samples per pixel)
-        s = np.sqrt(s_run ** 2 / chunks.shape[1] + s_run ** 2 * float(g["spp"]) / float(own_spp))
-        got = lum[m].mean()
-        allowed = max(0.005 * ref, 4.0 * s)
-        report.append((r, int(m.sum()), ref, got, (got - ref) / ref, allowed / ref))
-        assert abs(got - ref) <= allowed, "%s region %d (%d pixels): mean luminance %.5f against the reference's %.5f (%.2f %%, allowed %.2f %%)" % (
-            name, r, int(m.sum()), got, ref, 100 * (got - ref) / ref, 100 * allowed / ref)
-    total_ref, total = (mean * LUM).sum(-1).mean(), lum.mean()
-    assert abs(total - total_ref) <= 0.005 * total_ref, "%s: mean luminance %.5f against %.5f" % (name, total, total_ref)
-    return ok.mean(), report
+        if sizes[r] >= 24:
+            report.append((r, int(sizes[r])) + compare("region %d (%d pixels)" % (r, int(sizes[r])), lum[region == r].mean(), chunks[r]))
+    compare("whole image", lum.mean(), (chunks * sizes[:, None]).sum(axis=0) / sizes.sum())
+    return in4, report
