@@ -4,7 +4,8 @@ reference's sources), the standard error of that mean from the spread of its eig
 the camera ray meets, and each material region's mean luminance in every run.
 
 What is compared, and why these numbers:
-  * per pixel: |image - reference mean| <= 4 sigma on at least 98 % of the pixels and <= 5 sigma on at least 99 %,
+  * per pixel (pixels whose eight neighbours show the same material): |image - reference mean| <= 4 sigma on at least
+    98 % of them and <= 5 sigma on at least 99 %,
     sigma^2 = stderr^2 * (1 + reference samples / own samples) (the image under test has its own noise, scaled from the
     reference's by the sample counts), with a floor of 2e-4 of the pixel's value + 1e-5 for pixels without noise (a directly
     seen light). The standard error comes from eight runs (seven degrees of freedom) of samples with a heavy, clamped tail
@@ -55,7 +56,17 @@ def check(name, image, own_spp, g):
     sigma = np.sqrt(stderr ** 2 * (1.0 + ref_spp / float(own_spp)))
     floor = 2e-4 * np.abs(mean) + 1e-5
     dev = np.abs(image - mean)
-    in4, in5 = (dev <= 4.0 * sigma + floor).all(axis=-1).mean(), (dev <= 5.0 * sigma + floor).all(axis=-1).mean()
+    # Pixels on a material boundary are left out of the per-pixel count (not out of the region means): the camera has no
+    # jitter, so a centre ray that grazes a silhouette meets one surface or the other on a last-bit difference of the
+    # intersection arithmetic, and the whole pixel follows (the deterministic-image tests bound how many do).
+    pad = np.pad(region, 1, mode="edge")
+    h, w = region.shape
+    interior = np.ones((h, w), bool)
+    for dy in (0, 1, 2):
+        for dx in (0, 1, 2):
+            interior &= pad[dy:dy + h, dx:dx + w] == region
+    in4 = (dev <= 4.0 * sigma + floor).all(axis=-1)[interior].mean()
+    in5 = (dev <= 5.0 * sigma + floor).all(axis=-1)[interior].mean()
     assert in4 >= 0.98 and in5 >= 0.99, "%s: %.2f %% of the pixels within 4 sigma of the reference, %.2f %% within 5" % (name, 100 * in4, 100 * in5)
     lum = (image * LUM).sum(-1)
     chunks = g["region_lum"].astype(np.float64)  # (regions, runs); region 0 = camera rays that miss
