@@ -183,23 +183,26 @@ uint32_t po_pcg_hash(uint32_t v)
     uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
     return (w >> 22u) ^ w;
 }
-uint32_t po_path_key(uint32_t seed, uint32_t pixel, uint32_t sample)
+/* 64-bit key of a path: the lower half is one hash chain over (seed, pixel, sample), the upper half a second, independent
+ * one. Two paths draw the same numbers only if both halves agree. */
+uint64_t po_path_key(uint32_t seed, uint32_t pixel, uint32_t sample)
 {
-    uint32_t k = po_pcg_hash(seed);
-    k = po_pcg_hash(k ^ pixel);
+    uint32_t sh = po_pcg_hash(seed);
+    uint32_t k = po_pcg_hash(sh ^ pixel);
     k = po_pcg_hash(k + sample * 0x9E3779B9u);
-    return k;
+    uint32_t h = po_pcg_hash((sh ^ 0x68E31DA4u) + pixel * 0x9E3779B9u);
+    h = po_pcg_hash(h ^ (sample * 0x85EBCA6Bu));
+    return (uint64_t)k | ((uint64_t)h << 32);
 }
-/* Replaces Rand01 (PathTracer.cpp:13-16): uniform in [0,1) with 24 random bits. The draw counter enters through a
- * multiply and an exclusive-or, not an addition: key + counter would make the streams of two paths whose keys differ
- * by less than 256 share draws in shifted positions, and at 1080p x 1024 spp the 2^31 keys fill half of the 32-bit
- * space. */
-float po_rand01(uint32_t key, uint32_t bounce, uint32_t draw)
+/* Replaces Rand01 (PathTracer.cpp:13-16): uniform in [0,1) with 24 random bits. The draw counter, offset by the upper half
+ * of the key, enters the lower half through an exclusive-or, not an addition: key + counter would make the streams of two
+ * paths whose keys differ by less than 256 share draws in shifted positions. */
+float po_rand01(uint64_t key, uint32_t bounce, uint32_t draw)
 {
-    uint32_t r = po_pcg_hash(key ^ ((bounce * 8u + draw + 1u) * 0x9E3779B9u));
+    uint32_t r = po_pcg_hash((uint32_t)key ^ ((bounce * 8u + draw + 1u) * 0x9E3779B9u + (uint32_t)(key >> 32)));
     return (float)(r >> 8) * 5.9604644775390625e-8f;
 }
-typedef struct { uint32_t key, bounce, draw; uint32_t flags; v3 thr; } rng_t; /* flags/thr: extension state (Russian roulette) */
+typedef struct { uint64_t key; uint32_t bounce, draw; uint32_t flags; v3 thr; } rng_t; /* flags/thr: extension state (Russian roulette) */
 static inline float Rand01(rng_t* g) { return po_rand01(g->key, g->bounce, g->draw++); }
 
 /* ------------------------------------------------------------------ scene types */

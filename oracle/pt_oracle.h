@@ -126,8 +126,8 @@ void po_film_resolve(const float* accum, const uint32_t* samples, int n, int ton
 
 /* Random source shared with the GPU kernels. */
 uint32_t po_pcg_hash(uint32_t v);
-uint32_t po_path_key(uint32_t seed, uint32_t pixel, uint32_t sample);
-float po_rand01(uint32_t key, uint32_t bounce, uint32_t draw);
+uint64_t po_path_key(uint32_t seed, uint32_t pixel, uint32_t sample); /* lower half | upper half << 32 */
+float po_rand01(uint64_t key, uint32_t bounce, uint32_t draw);
 
 /* BVH statistics of mesh object `obj` (node count, max depth) for tests. */
 int po_mesh_bvh_stats(const po_scene*, int obj, uint32_t* nodes, uint32_t* depth);

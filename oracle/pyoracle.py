@@ -80,8 +80,8 @@ def lib():
         L.po_pcg_hash.argtypes = [C.c_uint32]
         L.po_pcg_hash.restype = C.c_uint32
         L.po_path_key.argtypes = [C.c_uint32] * 3
-        L.po_path_key.restype = C.c_uint32
-        L.po_rand01.argtypes = [C.c_uint32] * 3
+        L.po_path_key.restype = C.c_uint64
+        L.po_rand01.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.po_rand01.restype = C.c_float
         L.po_mesh_bvh_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         _lib = L

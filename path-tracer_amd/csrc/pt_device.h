@@ -31,7 +31,7 @@ PT_DEV float min3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, 
 
 // ---------------------------------------------------------------- random source
 // Counter-based replacement for the reference's thread_local mt19937 (PathTracer.cpp:8-16): a PCG
-// output hash keyed by (seed, pixel, sample, bounce, draw). Bit-identical to oracle/pt_oracle.c. The draw counter is
+// output hash keyed by (seed, pixel, sample, bounce, draw), with a 64-bit key per path. Bit-identical to oracle/pt_oracle.c. The draw counter is
 // mixed in by a multiply and an exclusive-or: added to the key it would let paths with nearby keys share draws.
 PT_DEV uint32_t pcg_hash(uint32_t v)
 {
@@ -44,18 +44,27 @@ PT_DEV uint32_t path_key(uint32_t seed_hash, uint32_t pixel, uint32_t sample)
     uint32_t k = pcg_hash(seed_hash ^ pixel);
     return pcg_hash(k + sample * 0x9E3779B9u);
 }
+// The upper half of the 64-bit path key: a second, independent hash chain over (seed, pixel, sample). It offsets the draw
+// counter, so two paths draw the same numbers only if both halves agree (2^-64 per pair; with the lower half alone a 4K
+// render at 16 384 samples per pixel would run every stream of random numbers about 32 times).
+PT_DEV uint32_t path_key_hi(uint32_t seed_hash, uint32_t pixel, uint32_t sample)
+{
+    uint32_t k = pcg_hash((seed_hash ^ 0x68E31DA4u) + pixel * 0x9E3779B9u);
+    return pcg_hash(k ^ (sample * 0x85EBCA6Bu));
+}
 constexpr uint32_t kDrawStep = 0x9E3779B9u;
-// The same value from a running counter: ctr = (bounce * 8 + draw + 1) * kDrawStep, advanced by kDrawStep per draw, so
-// that a bounce costs one multiply and each draw an add and an exclusive-or.
-PT_DEV uint32_t draw_counter(uint32_t bounce) { return (bounce * 8u + 1u) * kDrawStep; }
+// Draw number `draw` of bounce `bounce` hashes key ^ ((bounce * 8 + draw + 1) * kDrawStep + key_hi); as a running counter
+// ctr = draw_counter(bounce, key_hi), advanced by kDrawStep per draw, a bounce costs one multiply-add and each draw an
+// add and an exclusive-or.
+PT_DEV uint32_t draw_counter(uint32_t bounce, uint32_t key_hi) { return (bounce * 8u + 1u) * kDrawStep + key_hi; }
 PT_DEV float rand01c(uint32_t key, uint32_t ctr)
 {
     uint32_t r = pcg_hash(key ^ ctr);
     return (float)(r >> 8) * 5.9604644775390625e-8f;
 }
-PT_DEV float rand01(uint32_t key, uint32_t bounce, uint32_t draw)
+PT_DEV float rand01(uint32_t key, uint32_t key_hi, uint32_t bounce, uint32_t draw)
 {
-    uint32_t r = pcg_hash(key ^ ((bounce * 8u + draw + 1u) * 0x9E3779B9u));
+    uint32_t r = pcg_hash(key ^ ((bounce * 8u + draw + 1u) * 0x9E3779B9u + key_hi));
     return (float)(r >> 8) * 5.9604644775390625e-8f;
 }
 
@@ -897,7 +906,7 @@ PT_DEV float smith_g1(float c, float alpha) // PathTracer.cpp:157-163
 // One BSDF step of PathTracer::TraceRay (PathTracer.cpp:78-300) in throughput form.
 // Returns false when the path ends here (specular sample below the surface, PathTracer.cpp:141,239-240).
 // On true: ray/ior are the next segment and `weight` multiplies the throughput.
-PT_DEV bool sample_bsdf(const HitInfo& h, Ray& ray, float& ior, f3& weight, uint32_t key, uint32_t bounce)
+PT_DEV bool sample_bsdf(const HitInfo& h, Ray& ray, float& ior, f3& weight, uint32_t key, uint32_t key_hi, uint32_t bounce)
 {
     const float kTMin = 1e-4f;
     f3 n = normalize(h.n);
@@ -910,7 +919,7 @@ PT_DEV bool sample_bsdf(const HitInfo& h, Ray& ray, float& ior, f3& weight, uint
     f3 F0 = mk3(0.04f * om + h.albedo.x * h.metallic, 0.04f * om + h.albedo.y * h.metallic, 0.04f * om + h.albedo.z * h.metallic);
     float roughness = clampf(h.roughness, 0.0f, 1.0f);
     float alpha = fmaxf(1e-4f, roughness * roughness);
-    uint32_t ctr = draw_counter(bounce); // draws of this bounce, in order
+    uint32_t ctr = draw_counter(bounce, key_hi); // draws of this bounce, in order
     auto next = [&]() { const float u = rand01c(key, ctr); ctr += kDrawStep; return u; };
     const float pT = clampf(h.transmission, 0.0f, 1.0f);
     bool interfaceReflect = false;

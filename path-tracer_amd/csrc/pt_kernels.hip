@@ -65,7 +65,7 @@ constexpr int kNumCounters = 10;        // fields of ptamd_stats, in order
 #ifndef PT_WAVES_COOP
 #define PT_WAVES_COOP 4 // the cooperative traversal needs ~112 VGPRs; spilling them costs more than the fifth wave brings
 #endif
-constexpr int kLaneFloats = 3;          // per-lane floats parked in LDS: the film sum of the lane's pixel
+constexpr int kLaneFloats = 4;          // per-lane words parked in LDS: the film sum of the lane's pixel, the upper half of its path key
 template <bool LDS_GEOM, bool COUNT, bool EXT, bool TILED>
 __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void render_kernel(DScene sc, DRenderParams rp)
 {
@@ -123,6 +123,8 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
     f3 T = mk3(1.f, 1.f, 1.f), L = mk3(0.f, 0.f, 0.f);
     int bounce = 0;
     uint32_t key = path_key(seed_hash, pixel, s);
+    uint32_t* lds_key_hi = reinterpret_cast<uint32_t*>(lds_acc) + 3 * kBlock; // read once per bounce: not worth a register through the search
+    lds_key_hi[slot] = path_key_hi(seed_hash, pixel, s);
     uint32_t nrays = 0;
     TraversalCounts tc_total; tc_total.nodes = 0; tc_total.tris = 0; tc_total.node_trips = 0; tc_total.tri_trips = 0; tc_total.steal_rounds = 0;
     uint32_t ray_trips = 0, shade_lanes = 0, shade_trips = 0; // wave-level trips of the bounce loop and of its shading block
@@ -177,12 +179,13 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
                     done = true;                  // the next TraceRay would return 0 (PathTracer.cpp:35-36)
                 } else {
                     f3 w;
-                    done = !sample_bsdf(h, ray, ior, w, key, (uint32_t)bounce);
+                    const uint32_t keyHi = lds_key_hi[slot];
+                    done = !sample_bsdf(h, ray, ior, w, key, keyHi, (uint32_t)bounce);
                     T = T * w;
                     if (EXT && (rp.flags & kFlagRoulette) && bounce + 1 >= 3 && !done) {
                         // survive with probability q = clamp(max T, 0.05, 1), drawn from slot 7 of this bounce
                         float q = clampf(fmaxf(fmaxf(T.x, T.y), T.z), 0.05f, 1.0f);
-                        if (!(rand01(key, (uint32_t)bounce, 7u) < q)) done = true;
+                        if (!(rand01(key, keyHi, (uint32_t)bounce, 7u) < q)) done = true;
                         else T = T * __fdiv_rn(1.0f, q);
                     }
                     ++bounce;
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
             T = mk3(1.f, 1.f, 1.f); L = mk3(0.f, 0.f, 0.f);
             bounce = 0;
             key = path_key(seed_hash, pixel, s);
+            lds_key_hi[slot] = path_key_hi(seed_hash, pixel, s);
         }
     }
 
@@ -244,9 +248,11 @@ struct SampleTile {                  // per wave, in LDS
     uint32_t next;                   // ticket counter of the tile
     uint32_t pad[3];
 };
+static_assert(4 * kLaneFloats * kBlock == kLdsFixedBytes, "the host's residency decision counts these bytes");
 static_assert(sizeof(SampleTile) % 16 == 0, "the hit records behind the tiles are read 16 bytes at a time");
 constexpr uint32_t kSamplesTileBytes = 4 * sizeof(SampleTile);
 constexpr uint32_t kSamplesCacheBytes = 4 * 16 * 5 * 16; // [wave][pixel][5 float4]
+constexpr uint32_t kSamplesKeyBytes = 4 * kBlock;        // the upper half of each lane's path key
 PT_DEV unsigned long long to_fixed(float c)
 {
     if (c < 0.0f) return (unsigned long long)__float2ll_rn(c * kFxScale); // not a radiance this renderer produces; kept exact anyway
@@ -282,7 +288,8 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
     const int wave = __builtin_amdgcn_readfirstlane(slot >> 6); // wave-uniform by construction: tile addresses and origins stay in scalar registers
     SampleTile& tile = reinterpret_cast<SampleTile*>(lds_raw + stackBytes)[wave];
     float4* cache = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes) + wave * (16 * 5);
-    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes);
+    uint32_t* lds_key_hi = reinterpret_cast<uint32_t*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes);
+    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes);
     const int p0 = lane & 15; // the pixel this lane traces the camera ray of, with three others
     const bool first = lane < 16;
     if (lane == 0) tile.next = 0u;
@@ -390,6 +397,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
             else { q = nvalid > 1u ? __umulhi(t, magic) : t; pi = tile.list[t - q * nvalid]; }
             const uint32_t pixel = (uint32_t)((ty0 + (int)(pi >> 2)) * W + tx0 + (int)(pi & 3u));
             key = path_key(seed_hash, pixel, rp.spp_begin + q);
+            lds_key_hi[slot] = path_key_hi(seed_hash, pixel, rp.spp_begin + q);
             // the camera ray's hit comes from the tile's record
             const float4* rec = cache + pi * 5u;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
@@ -403,11 +411,12 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
         }
         if (COUNT) { ++shade_lanes; if (wave_leader()) ++shade_trips; }
         f3 w;
-        bool done = !sample_bsdf(h, ray, ior, w, key, (uint32_t)bounce);
+        const uint32_t keyHi = lds_key_hi[slot];
+        bool done = !sample_bsdf(h, ray, ior, w, key, keyHi, (uint32_t)bounce);
         T = T * w;
         if (EXT && (rp.flags & kFlagRoulette) && bounce + 1 >= 3 && !done) {
             float q = clampf(fmaxf(fmaxf(T.x, T.y), T.z), 0.05f, 1.0f);
-            if (!(rand01(key, (uint32_t)bounce, 7u) < q)) done = true;
+            if (!(rand01(key, keyHi, (uint32_t)bounce, 7u) < q)) done = true;
             else T = T * __fdiv_rn(1.0f, q);
         }
         ++bounce;
@@ -543,7 +552,7 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     // Fewer than 64 samples leave its waves too short-lived; albedo-only and depth < 2 renders end at the camera ray's hit
     // anyway. PTAMD_NO_SAMPLE_MAJOR=1 (read per launch) keeps every launch on the pixel-major kernel.
     const bool noSampleMajor = getenv("PTAMD_NO_SAMPLE_MAJOR") != nullptr;
-    const size_t ldsSamples = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + geomBytes;
+    const size_t ldsSamples = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes + geomBytes;
     if (fits && !tiled && !noSampleMajor && rp.spp_count >= 64u && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only
         && ldsSamples <= kLdsBlockBytes) {
         const int nb = ((rp.tiles_x * rp.tiles_y + 63) / 64) * 64; // one workgroup per 8x8-pixel block, dealt to the XCDs eight neighbours at a time

@@ -91,7 +91,7 @@ constexpr uint32_t kLdsNodeBytes = 112;
 // workgroups per CU. What has to fit: the traversal stack (1 KB per tree level), 3 KB of film sums, the LDS nodes
 // and the hot triangles.
 constexpr uint32_t kLdsBlockBytes = 160 * 1024 / 3;
-constexpr uint32_t kLdsFixedBytes = 3 * 1024; // per workgroup, besides stack and geometry
+constexpr uint32_t kLdsFixedBytes = 4 * 1024; // per workgroup, besides stack and geometry
 
 // Hot triangle in plane form. With n = e1 x e2 (e1 = v1 - v0, e2 = v2 - v0): the determinant of Mesh::RayTriMT
 // (Mesh.cpp:421-431) is -(n . d), its t is (n . v0 - n . o) / (n . d), and the barycentrics of the hit point h

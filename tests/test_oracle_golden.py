@@ -107,6 +107,8 @@ def test_rng_is_counter_based_and_uniform():
     assert L.po_pcg_hash(0) == 129708002  # PCG RXS-M-XS of 0 (fixed vector: guards the constants)
     k = L.po_path_key(0x5EED, 1234, 7)
     assert k == L.po_path_key(0x5EED, 1234, 7) and k != L.po_path_key(0x5EED, 1235, 7)
+    assert (k >> 32) != 0 and (k >> 32) != (k & 0xFFFFFFFF)  # a 64-bit key: two hash chains
+    assert (k >> 32) != (L.po_path_key(0x5EED, 1234, 8) >> 32) and (k >> 32) != (L.po_path_key(0x5EEE, 1234, 7) >> 32)
     u = np.array([L.po_rand01(L.po_path_key(1, p, s), b, d) for p in range(40) for s in range(10) for b in range(4) for d in range(5)])
     assert u.min() >= 0.0 and u.max() < 1.0
     assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
