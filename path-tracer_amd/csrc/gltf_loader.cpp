@@ -166,66 +166,140 @@ std::string dir_of(const std::string& path)
 }
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
-// 8-bit non-interlaced PNG -> RGBA8 (what stb_image hands tinygltf with req_comp = 4, tiny_gltf.h:2653).
+// PNG -> the RGBA bytes the reference's Mesh samples (Mesh.cpp:15-37). tinygltf asks stb_image for four channels
+// (tiny_gltf.h:2653) and the decode below follows what stb_image does with every flavour it accepts: bit depths 1, 2, 4
+// (grey scaled to 8 bits by 255, 85, 17; palette indices as they are), 8 and 16, colour types 0, 2, 3, 4, 6, Adam7
+// interlacing, palette transparency and colour-key transparency (the key of a low-depth grey image scaled like its pixels).
+// A 16-bit file is special: tinygltf loads it as 16-bit samples (tiny_gltf.h:2645-2661), ModelLoader copies that buffer
+// as it is (ModelLoader.h:190-197) and the sampler indexes it as if it held bytes, so a texel is made of the low and high
+// bytes of two 16-bit samples of the image's first half. The bytes returned here are that first half.
 void decode_png_rgba(const uint8_t* data, size_t size, int& w, int& h, std::vector<uint8_t>& rgba)
 {
     static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
     if (size < 8 || std::memcmp(data, sig, 8)) throw std::runtime_error("image: only PNG and JPEG images are supported");
     size_t pos = 8;
     std::vector<uint8_t> idat, plte, trns;
-    int depth = 0, ctype = 0, interlace = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    bool haveTrns = false;
     w = h = 0;
     while (pos + 8 <= size) {
         uint32_t n = be32(data + pos);
         const uint8_t* tag = data + pos + 4;
         const uint8_t* body = data + pos + 8;
-        if (pos + 12 + n > size) throw std::runtime_error("image: truncated PNG");
+        if ((uint64_t)pos + 12 + n > size) throw std::runtime_error("image: truncated PNG");
         if (!std::memcmp(tag, "IHDR", 4)) { if (n != 13) throw std::runtime_error("image: bad PNG header");
-                                           w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+                                           w = (int)be32(body); h = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+                                           if (body[10] || body[11]) throw std::runtime_error("image: bad PNG compression or filter method"); }
         else if (!std::memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), body, body + n);
         else if (!std::memcmp(tag, "PLTE", 4)) plte.assign(body, body + n);
-        else if (!std::memcmp(tag, "tRNS", 4)) trns.assign(body, body + n);
+        else if (!std::memcmp(tag, "tRNS", 4)) { trns.assign(body, body + n); haveTrns = true; }
         else if (!std::memcmp(tag, "IEND", 4)) break;
-        pos += 12 + n;
+        pos += 12 + (size_t)n;
     }
-    if (depth != 8 || interlace != 0) throw std::runtime_error("image: only 8-bit non-interlaced PNG is supported");
-    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!ch || w <= 0 || h <= 0) throw std::runtime_error("image: unsupported PNG colour type");
-    size_t stride = (size_t)w * ch;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16) throw std::runtime_error("image: PNG bit depth must be 1, 2, 4, 8 or 16");
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch || w <= 0 || h <= 0 || interlace > 1) throw std::runtime_error("image: unsupported PNG colour type");
+    if (ctype == 3 && depth == 16) throw std::runtime_error("image: a PNG palette image cannot be 16-bit");
+    if (ctype == 3 && plte.empty()) throw std::runtime_error("image: PNG palette image without a palette");
+    if ((uint64_t)w * (uint64_t)h > (1ull << 28)) throw std::runtime_error("image: PNG too large");
+    if (haveTrns && ctype != 3 && ((ctype & 4) || trns.size() != (size_t)ch * 2)) throw std::runtime_error("image: bad PNG tRNS chunk");
+
+    // pass geometry: one pass, or the seven of Adam7
+    struct Pass { int x0, y0, dx, dy; };
+    static const Pass adam7[7] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+    static const Pass whole = { 0, 0, 1, 1 };
+    const int numPasses = interlace ? 7 : 1;
+    const size_t bpp = (size_t)std::max(1, ch * depth / 8); // filter distance in bytes
+    auto row_bytes = [&](int pw) { return ((size_t)pw * ch * depth + 7) / 8; };
+    size_t rawSize = 0;
+    for (int k = 0; k < numPasses; ++k) {
+        const Pass& ps = interlace ? adam7[k] : whole;
+        const int pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (pw > 0 && ph > 0) rawSize += (row_bytes(pw) + 1) * (size_t)ph;
+    }
+    std::vector<uint8_t> raw(rawSize);
     uLongf rawLen = (uLongf)raw.size();
-    if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size())
-        throw std::runtime_error("image: PNG inflate failed");
-    std::vector<uint8_t> img(stride * (size_t)h);
-    for (int y = 0; y < h; ++y) {
-        const uint8_t* in = &raw[(stride + 1) * (size_t)y];
-        uint8_t ft = in[0];
-        ++in;
-        uint8_t* cur = &img[stride * (size_t)y];
-        const uint8_t* prev = y ? &img[stride * (size_t)(y - 1)] : nullptr;
-        for (size_t i = 0; i < stride; ++i) {
-            int a = i >= (size_t)ch ? cur[i - ch] : 0, b = prev ? prev[i] : 0, c = (prev && i >= (size_t)ch) ? prev[i - ch] : 0;
-            int pred = 0;
-            switch (ft) {
-            case 0: pred = 0; break; case 1: pred = a; break; case 2: pred = b; break; case 3: pred = (a + b) >> 1; break;
-            case 4: { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                      pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-            default: throw std::runtime_error("image: bad PNG filter");
+    const int zrc = uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size());
+    if ((zrc != Z_OK && zrc != Z_BUF_ERROR) || rawLen != raw.size()) throw std::runtime_error("image: PNG inflate failed");
+
+    // unfilter every pass and scatter its samples (as stored: 1..16 bits each) into the full image
+    std::vector<uint16_t> sample((size_t)w * h * ch);
+    size_t at = 0;
+    for (int k = 0; k < numPasses; ++k) {
+        const Pass& ps = interlace ? adam7[k] : whole;
+        const int pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t stride = row_bytes(pw);
+        std::vector<uint8_t> prev(stride, 0), cur(stride);
+        for (int j = 0; j < ph; ++j) {
+            const uint8_t ft = raw[at];
+            const uint8_t* in = &raw[at + 1];
+            at += stride + 1;
+            if (ft > 4) throw std::runtime_error("image: bad PNG filter");
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                int pred = 0;
+                switch (ft) {
+                case 1: pred = a; break; case 2: pred = b; break; case 3: pred = (a + b) >> 1; break;
+                case 4: { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                default: break;
+                }
+                cur[i] = (uint8_t)(in[i] + pred);
             }
-            cur[i] = (uint8_t)(in[i] + pred);
+            const size_t y = (size_t)ps.y0 + (size_t)j * ps.dy;
+            for (int i = 0; i < pw; ++i) {
+                uint16_t* out = &sample[(y * w + (size_t)ps.x0 + (size_t)i * ps.dx) * ch];
+                for (int c2 = 0; c2 < ch; ++c2) {
+                    const size_t s = (size_t)i * ch + c2;
+                    if (depth == 16) out[c2] = (uint16_t)((cur[2 * s] << 8) | cur[2 * s + 1]);
+                    else if (depth == 8) out[c2] = cur[s];
+                    else { const size_t bit = s * depth; out[c2] = (uint16_t)((cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1)); }
+                }
+            }
+            prev.swap(cur);
         }
     }
-    rgba.assign((size_t)w * h * 4, 255);
-    for (size_t p = 0; p < (size_t)w * h; ++p) {
+
+    const size_t npx = (size_t)w * h;
+    if (depth == 16) {
+        // 16-bit RGBA in the machine's byte order (low byte first), of which the tracer's sampler sees the first half as bytes
+        const uint16_t key[3] = { haveTrns ? (uint16_t)((trns[0] << 8) | trns[1]) : (uint16_t)0,
+                                  haveTrns && ch == 3 ? (uint16_t)((trns[2] << 8) | trns[3]) : (uint16_t)0,
+                                  haveTrns && ch == 3 ? (uint16_t)((trns[4] << 8) | trns[5]) : (uint16_t)0 };
+        rgba.assign(npx * 4, 0);
+        for (size_t p = 0; p < (npx + 1) / 2; ++p) { // pixels whose 8 bytes lie in the first half
+            const uint16_t* s = &sample[p * ch];
+            uint16_t px[4] = { 0, 0, 0, 0xFFFF };
+            switch (ctype) {
+            case 0: px[0] = px[1] = px[2] = s[0]; if (haveTrns && s[0] == key[0]) px[3] = 0; break;
+            case 2: px[0] = s[0]; px[1] = s[1]; px[2] = s[2]; if (haveTrns && s[0] == key[0] && s[1] == key[1] && s[2] == key[2]) px[3] = 0; break;
+            case 4: px[0] = px[1] = px[2] = s[0]; px[3] = s[1]; break;
+            default: px[0] = s[0]; px[1] = s[1]; px[2] = s[2]; px[3] = s[3]; break;
+            }
+            for (int k = 0; k < 4; ++k) {
+                const size_t byte = p * 8 + (size_t)k * 2;
+                if (byte < npx * 4) rgba[byte] = (uint8_t)(px[k] & 255);
+                if (byte + 1 < npx * 4) rgba[byte + 1] = (uint8_t)(px[k] >> 8);
+            }
+        }
+        return;
+    }
+    const int scale = (ctype == 0 && depth < 8) ? (depth == 1 ? 255 : depth == 2 ? 85 : 17) : 1;
+    uint8_t key[3] = { 0, 0, 0 };
+    if (haveTrns && ctype != 3) for (int k = 0; k < ch; ++k) key[k] = (uint8_t)(trns[2 * k + 1] * scale); // the low byte of the key, scaled like the pixels
+    rgba.assign(npx * 4, 255);
+    for (size_t p = 0; p < npx; ++p) {
         uint8_t* o = &rgba[4 * p];
-        const uint8_t* s = &img[p * ch];
+        const uint16_t* s = &sample[p * ch];
         switch (ctype) {
-        case 0: o[0] = o[1] = o[2] = s[0]; break;
-        case 2: o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; break;
-        case 3: { size_t k = s[0]; if (3 * k + 2 < plte.size()) { o[0] = plte[3 * k]; o[1] = plte[3 * k + 1]; o[2] = plte[3 * k + 2]; }
+        case 0: o[0] = o[1] = o[2] = (uint8_t)(s[0] * scale); if (haveTrns && o[0] == key[0]) o[3] = 0; break;
+        case 2: o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2];
+                if (haveTrns && o[0] == key[0] && o[1] == key[1] && o[2] == key[2]) o[3] = 0; break;
+        case 3: { const size_t k = s[0]; if (3 * k + 2 < plte.size()) { o[0] = plte[3 * k]; o[1] = plte[3 * k + 1]; o[2] = plte[3 * k + 2]; }
                   if (k < trns.size()) o[3] = trns[k]; break; }
-        case 4: o[0] = o[1] = o[2] = s[0]; o[3] = s[1]; break;
-        case 6: o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; break;
+        case 4: o[0] = o[1] = o[2] = (uint8_t)s[0]; o[3] = (uint8_t)s[1]; break;
+        default: o[0] = (uint8_t)s[0]; o[1] = (uint8_t)s[1]; o[2] = (uint8_t)s[2]; o[3] = (uint8_t)s[3]; break;
         }
     }
 }

@@ -95,6 +95,140 @@ def jpeg_pictures():
     return out
 
 
+ADAM7 = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+
+
+def png_encode_any(samples, depth, ctype, interlace=False, palette=None, trns=None):
+    """A PNG file of any flavour the format allows. samples: (H, W, C) integers below 2^depth, C = channels of the colour
+    type (1 for grey and for palette indices). Rows are filtered with the five filter types in turn."""
+    import struct
+    import zlib
+    h, w, c = samples.shape
+    assert c == {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, c * depth // 8)
+
+    def pack(rows):  # (h', w', c) -> list of bytes per row
+        out = []
+        for r in rows:
+            flat = r.reshape(-1).astype(np.uint32)
+            if depth == 16:
+                out.append(flat.astype(">u2").tobytes())
+            elif depth == 8:
+                out.append(flat.astype(np.uint8).tobytes())
+            else:
+                per = 8 // depth
+                pad = (-len(flat)) % per
+                f = np.concatenate([flat, np.zeros(pad, np.uint32)]).reshape(-1, per)
+                byte = np.zeros(len(f), np.uint32)
+                for k in range(per):
+                    byte |= f[:, k] << (8 - depth * (k + 1))
+                out.append(byte.astype(np.uint8).tobytes())
+        return out
+
+    def filtered(rows, start):
+        out = bytearray()
+        prev = bytes(len(rows[0])) if rows else b""
+        for i, row in enumerate(rows):
+            ft = (start + i) % 5
+            line = bytearray(len(row))
+            for k in range(len(row)):
+                a = row[k - bpp] if k >= bpp else 0
+                b = prev[k]
+                cc = prev[k - bpp] if k >= bpp else 0
+                if ft == 0:
+                    pred = 0
+                elif ft == 1:
+                    pred = a
+                elif ft == 2:
+                    pred = b
+                elif ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    pp = a + b - cc
+                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - cc)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)
+                line[k] = (row[k] - pred) & 255
+            out.append(ft)
+            out += line
+            prev = row
+        return bytes(out)
+
+    raw = b""
+    if interlace:
+        for n, (x0, y0, dx, dy) in enumerate(ADAM7):
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filtered(pack(sub), n)
+    else:
+        raw = filtered(pack(samples), 1)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    comp = zlib.compress(raw, 6)
+    half = len(comp) // 2  # two IDAT chunks: decoders must join them
+    return out + chunk(b"IDAT", comp[:half]) + chunk(b"IDAT", comp[half:]) + chunk(b"IEND", b"")
+
+
+def png_pictures():
+    """PNG files covering what stb_image (the reference's decoder, through tinygltf) accepts beyond 8-bit non-interlaced
+    colour: bit depths 1, 2, 4 and 16, palettes with and without transparency, colour-key transparency, grey + alpha,
+    Adam7 interlacing (sizes that leave some passes empty included)."""
+    import struct
+    rng = np.random.default_rng(17)
+
+    def img(w, h, c, depth):
+        return rng.integers(0, 1 << depth, (h, w, c), dtype=np.uint32)
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    pal256 = rng.integers(0, 256, (256, 3), dtype=np.uint8)
+    files = [
+        png_encode_any(img(13, 9, 3, 8), 8, 2, interlace=True),
+        png_encode_any(img(8, 8, 4, 8), 8, 6, interlace=True),
+        png_encode_any(img(3, 2, 4, 8), 8, 6, interlace=True),          # passes 2..6 partly empty
+        png_encode_any(img(1, 1, 3, 8), 8, 2, interlace=True),
+        png_encode_any(img(17, 5, 1, 1), 1, 0), png_encode_any(img(10, 7, 1, 2), 2, 0), png_encode_any(img(9, 6, 1, 4), 4, 0),
+        png_encode_any(img(11, 7, 1, 4), 4, 0, interlace=True),
+        png_encode_any(img(12, 5, 1, 4), 4, 3, palette=pal), png_encode_any(img(7, 9, 1, 2), 2, 3, palette=pal[:4]),
+        png_encode_any(img(15, 4, 1, 1), 1, 3, palette=pal[:2], trns=[40]),
+        png_encode_any(img(9, 9, 1, 8), 8, 3, palette=pal256, trns=list(rng.integers(0, 256, 100)), interlace=True),
+        png_encode_any(img(10, 6, 2, 8), 8, 4), png_encode_any(img(10, 6, 1, 8), 8, 0, trns=struct.pack(">H", 77)),
+        png_encode_any(np.minimum(img(10, 6, 3, 8), 3), 8, 2, trns=struct.pack(">HHH", 1, 2, 3)),
+        png_encode_any(np.minimum(img(12, 5, 1, 2), 3), 2, 0, trns=struct.pack(">H", 2)),
+        png_encode_any(img(7, 5, 3, 16), 16, 2), png_encode_any(img(6, 4, 4, 16), 16, 6, interlace=True),
+        png_encode_any(img(9, 3, 1, 16), 16, 0), png_encode_any(img(5, 5, 2, 16), 16, 4),
+        png_encode_any(img(6, 6, 1, 16) & 0x0303, 16, 0, trns=struct.pack(">H", 0x0101)),
+    ]
+    return files
+
+
+def write_png_fixtures():
+    """png_cases.npz: the PNG files above + the bytes ModelLoader holds for each after loading them through the reference
+    (ref_oracle images). A 16-bit file arrives as 16-bit samples (tiny_gltf.h:2645-2661) that ModelLoader copies as they are
+    (ModelLoader.h:190-197), so its entry is twice as long as width * height * channels."""
+    import subprocess
+    import tempfile
+    files = png_pictures()
+    prim = gltf_io.box_primitive((0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    mat = gltf_io.gltf_material("m", presets.material())
+    tmp = os.path.join(tempfile.mkdtemp(prefix="ptpng_"), "cases.glb")
+    gltf_io.write_glb(tmp, [prim], [mat], files)
+    pre = os.path.join(os.path.dirname(tmp), "im")
+    subprocess.run([po.REF_BIN, "images", tmp, pre], check=True, capture_output=True)
+    out = {}
+    for i, line in enumerate(open(pre + ".txt")):
+        w, h, c = map(int, line.split())
+        out["file_%d" % i] = np.frombuffer(files[i], np.uint8)
+        out["size_%d" % i] = np.array([w, h, c], np.int32)
+        out["bytes_%d" % i] = np.fromfile("%s.%d.u8" % (pre, i), np.uint8)
+    assert len(out) == 3 * len(files)
+    np.savez_compressed(os.path.join(HERE, "png_cases.npz"), **out)
+    return out
+
+
 def reference_images(glb):
     """The texels ModelLoader holds after loading glb (ref_oracle images): list of (H, W, C) uint8."""
     import subprocess
@@ -220,6 +354,7 @@ def main():
     dragon.write_dragon_field(field)
     if not only or "textured_jpeg" in only:
         write_jpeg_fixtures()
+        write_png_fixtures()
     late = {"textured_jpeg": (presets.mixed("tests/golden/textured_jpeg.glb", 96, 96, mesh_pos=(2.7, 1.6, 2.6), mesh_rot=(0.0, 25.0, 0.0),
                                             mesh_scale=(1.4, 1.4, 1.4)), 6)}
     late.update(dragon_scenes(field))

@@ -215,6 +215,49 @@ def test_jpeg_images_decode_to_the_reference_texels(tmp_path):
             assert "JPEG" in str(e) or "image" in str(e)
 
 
+def test_png_flavours_decode_to_the_reference_bytes():
+    """Everything stb_image (the reference's decoder, through tinygltf) accepts as PNG: bit depths 1 / 2 / 4 / 16, palettes
+    with and without transparency, colour-key transparency, grey + alpha, Adam7 interlacing. 21 files (written by
+    tests/golden/make_golden.py; png_cases.npz keeps them with the bytes the reference's ModelLoader held after loading
+    each). The texel bytes must be identical. A 16-bit file reaches the reference's sampler as 16-bit samples read as
+    bytes (tiny_gltf.h:2645-2661, ModelLoader.h:190-197, Mesh.cpp:31-34): what it can index is the first width * height * 4
+    bytes of that buffer, and that is what the loader must return."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "png_cases.npz"))
+    n = sum(1 for k in g.files if k.startswith("file_"))
+    assert n == 21
+    sixteen = 0
+    for i in range(n):
+        w, h, c = (int(v) for v in g["size_%d" % i])
+        held = g["bytes_%d" % i]
+        assert c == 4 and len(held) in (w * h * 4, w * h * 8)
+        sixteen += len(held) == w * h * 8
+        got = ptamd.decode_image(g["file_%d" % i].tobytes())
+        assert got.shape == (h, w, 4) and np.array_equal(got.reshape(-1), held[:w * h * 4]), i
+    assert sixteen == 5
+    # and through the model loader
+    prim = gltf_io.box_primitive((0, 0, 0), (0, 0, 0), (1, 1, 1), 0)
+    mat = gltf_io.gltf_material("m", [1, 1, 1, 1.0, 0.0, 1, 1, 1, 0.0, 1.5, 0.0])
+    import tempfile
+    path = os.path.join(tempfile.mkdtemp(prefix="ptpng_"), "cases.glb")
+    gltf_io.write_glb(path, [prim], [mat], [g["file_%d" % i].tobytes() for i in (0, 8, 17)])
+    imgs = ptamd.load_model(path)["images"]
+    for k, i in enumerate((0, 8, 17)):
+        assert np.array_equal(imgs[k].reshape(-1), g["bytes_%d" % i][:imgs[k].size])
+    # truncated and corrupted files end in a clean error or an image, never a crash
+    raw = g["file_11"].tobytes()
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        m = bytearray(raw[:int(rng.integers(20, len(raw) + 1))] if trial % 2 else raw)
+        for _ in range(int(rng.integers(1, 4))):
+            m[int(rng.integers(8, len(m)))] = int(rng.integers(0, 256))
+        try:
+            ptamd.decode_image(bytes(m))
+        except ptamd.PtamdError as e:
+            assert "image" in str(e) or "PNG" in str(e)
+
+
 def test_jpeg_header_that_claims_more_than_the_file_holds_is_refused():
     """A forged frame header: a small file whose SOF claims 23170 x 23170 pixels would make the decoder allocate
     gigabytes of component planes before reading a single coefficient. It is refused from the header alone."""
