@@ -154,12 +154,13 @@ int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3]);
 /* No reference counterpart (a miss returns the constant above, PathTracer.cpp:59-60): a cubemap whose
  * texel replaces that constant. faces: +x, -x, +y, -y, +z, -z, each face_size x face_size RGBA8, row 0 at
  * the top, OpenGL cubemap orientation; radiance = texel / 255 * intensity (nearest texel, no sRGB decode).
- * faces == NULL or face_size <= 0 removes it. Takes effect at once; no commit needed. */
+ * faces == NULL or face_size <= 0 removes it. Takes effect at once; no commit needed. Limit 4096 x 4096 per face (the map
+ * is kept as float radiance on the device, 1.6 GB at that size). */
 int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const faces[6], float intensity);
 /* The same with float radiance (an HDR map; no reference counterpart either): each face is face_size x face_size texels
  * of three floats (r, g, b), row 0 at the top; a miss returns the nearest texel as it is -- no intensity factor, no upper
  * bound (Film::AddSample still clips each sample's luminance at 12, Film.cpp:38-43). Replaces an RGBA8 map and vice
- * versa. faces == NULL or face_size <= 0 removes it. Limit 4096 x 4096 per face (1.6 GB on the device). */
+ * versa. faces == NULL or face_size <= 0 removes it. Same limit. */
 int ptamd_scene_set_skybox_f32(ptamd_scene* s, int face_size, const float* const faces[6]);
 /* Flattens the object list into SoA device buffers, builds and linearises the per-mesh BVHs
  * (replaces Mesh::BuildBVH, Mesh.cpp:289-397) and uploads. Re-callable after edits; trees are built once per

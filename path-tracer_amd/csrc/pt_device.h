@@ -1024,8 +1024,8 @@ PT_DEV Ray camera_ray(const DCamera& cam, int px, int py)
 }
 
 // Miss radiance from the cubemap (an extension: the reference only has the constant of PathTracer.h:21).
-// OpenGL face selection and orientation, nearest texel; RGBA8 maps give texel / 255 * intensity (no sRGB decode), float
-// maps give their texel.
+// OpenGL face selection and orientation, nearest texel. The map is stored as float radiance, one 16-byte read per lookup:
+// RGBA8 maps were converted at upload (texel / 255 * intensity, no sRGB decode), float maps are kept as they came.
 PT_DEV f3 sky_lookup(const DScene& sc, f3 d)
 {
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
@@ -1037,14 +1037,8 @@ PT_DEV f3 sky_lookup(const DScene& sc, f3 d)
     const int n = sc.sky_size;
     int x = (int)(u * (float)n), y = (int)(v * (float)n);
     x = min(max(x, 0), n - 1); y = min(max(y, 0), n - 1);
-    const size_t texel = ((size_t)face * n + y) * n + x;
-    if (sc.sky_format != 0) { // float radiance, taken as it is (no intensity factor, no upper bound)
-        const float4 r = reinterpret_cast<const float4*>(sc.sky)[texel];
-        return mk3(r.x, r.y, r.z);
-    }
-    uint32_t px = sc.sky[texel];
-    f3 c = mk3(__fdiv_rn((float)(px & 255u), 255.0f), __fdiv_rn((float)((px >> 8) & 255u), 255.0f), __fdiv_rn((float)((px >> 16) & 255u), 255.0f));
-    return c * sc.sky_intensity;
+    const float4 r = sc.sky[((size_t)face * n + y) * n + x];
+    return mk3(r.x, r.y, r.z);
 }
 
 } // namespace ptamd

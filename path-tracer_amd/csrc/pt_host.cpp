@@ -102,7 +102,7 @@ struct ptamd_scene {
     DevBuf<DObject> d_objects; DevBuf<DMesh> d_meshes; DevBuf<DMaterial> d_materials;
     DevBuf<DNode> d_nodes; DevBuf<DWideNode> d_wide; DevBuf<float> d_lds_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
-    DevBuf<uint32_t> d_sky; int sky_size = 0; float sky_intensity = 1.0f; int sky_format = 0;
+    DevBuf<float> d_sky; int sky_size = 0;
     unsigned long long* d_counters = nullptr; // this scene's PTAMD_FLAG_COUNT tallies (allocated by its first counting render)
     DScene dscene;
     void release() // what commit rebuilds; the sky map is uploaded by its own call and outlives commits
@@ -498,16 +498,17 @@ int ptamd_scene_set_background(ptamd_scene* s, const float rgb[3])
     return PTAMD_OK;
 }
 
-// Both sky entry points end here: `tex` holds the six faces in device form (one word per RGBA8 texel, four per float texel).
-static int upload_sky(ptamd_scene* s, int face_size, const std::vector<uint32_t>& tex, int format, float intensity)
+// Both sky entry points end here: `tex` holds the six faces as float radiance, four floats per texel (rgb + one unused:
+// a texel is one 16-byte read).
+static int upload_sky(ptamd_scene* s, int face_size, const std::vector<float>& tex)
 {
     if (int rc = s->d_sky.upload(tex)) { // the old map is gone and the new one did not arrive: fall back to the constant background
         s->d_sky.release(); s->sky_size = 0;
         s->dscene.sky = nullptr; s->dscene.sky_size = 0;
         return rc;
     }
-    s->sky_size = face_size; s->sky_intensity = intensity; s->sky_format = format;
-    s->dscene.sky = s->d_sky.ptr; s->dscene.sky_size = face_size; s->dscene.sky_intensity = intensity; s->dscene.sky_format = format;
+    s->sky_size = face_size;
+    s->dscene.sky = reinterpret_cast<const float4*>(s->d_sky.ptr); s->dscene.sky_size = face_size;
     return PTAMD_OK;
 }
 static int clear_sky(ptamd_scene* s)
@@ -516,19 +517,26 @@ static int clear_sky(ptamd_scene* s)
     s->dscene.sky = nullptr; s->dscene.sky_size = 0;
     return PTAMD_OK;
 }
+static int check_sky_faces(int face_size, const void* const* faces)
+{
+    if (face_size > 4096) return fail(PTAMD_ERR_LIMIT, "skybox faces are limited to 4096 x 4096");
+    for (int f = 0; f < 6; ++f) if (!faces[f]) return fail(PTAMD_ERR_ARG, "null skybox face");
+    return PTAMD_OK;
+}
 
 int ptamd_scene_set_skybox(ptamd_scene* s, int face_size, const uint8_t* const faces[6], float intensity)
 {
     if (int rc = check_scene(s)) return rc;
     if (!faces || face_size <= 0) return clear_sky(s);
     if (int rc = need_init()) return rc;
-    if (face_size > 8192) return fail(PTAMD_ERR_LIMIT, "skybox faces are limited to 8192 x 8192");
-    for (int f = 0; f < 6; ++f) if (!faces[f]) return fail(PTAMD_ERR_ARG, "null skybox face");
+    if (int rc = check_sky_faces(face_size, reinterpret_cast<const void* const*>(faces))) return rc;
     const size_t n = (size_t)face_size * face_size;
     try {
-        std::vector<uint32_t> tex(6 * n);
-        for (int f = 0; f < 6; ++f) std::memcpy(tex.data() + f * n, faces[f], n * 4);
-        return upload_sky(s, face_size, tex, 0, intensity);
+        std::vector<float> tex(6 * n * 4, 0.0f);
+        for (int f = 0; f < 6; ++f)
+            for (size_t p = 0; p < n; ++p)
+                for (int k = 0; k < 3; ++k) tex[(f * n + p) * 4 + k] = ((float)faces[f][4 * p + k] / 255.0f) * intensity; // texel / 255 * intensity, rounded like that
+        return upload_sky(s, face_size, tex);
     } catch (const std::exception& e) { return fail(PTAMD_ERR_LIMIT, e.what()); }
 }
 
@@ -537,14 +545,13 @@ int ptamd_scene_set_skybox_f32(ptamd_scene* s, int face_size, const float* const
     if (int rc = check_scene(s)) return rc;
     if (!faces || face_size <= 0) return clear_sky(s);
     if (int rc = need_init()) return rc;
-    if (face_size > 4096) return fail(PTAMD_ERR_LIMIT, "float skybox faces are limited to 4096 x 4096");
-    for (int f = 0; f < 6; ++f) if (!faces[f]) return fail(PTAMD_ERR_ARG, "null skybox face");
+    if (int rc = check_sky_faces(face_size, reinterpret_cast<const void* const*>(faces))) return rc;
     const size_t n = (size_t)face_size * face_size;
     try {
-        std::vector<uint32_t> tex(6 * n * 4, 0u); // rgb + one unused word: a texel is one 16-byte read
+        std::vector<float> tex(6 * n * 4, 0.0f);
         for (int f = 0; f < 6; ++f)
             for (size_t p = 0; p < n; ++p) std::memcpy(&tex[(f * n + p) * 4], faces[f] + 3 * p, 12);
-        return upload_sky(s, face_size, tex, 1, 1.0f);
+        return upload_sky(s, face_size, tex);
     } catch (const std::exception& e) { return fail(PTAMD_ERR_LIMIT, e.what()); }
 }
 
@@ -809,7 +816,7 @@ static int commit_scene(ptamd_scene* s)
     ds.shade = reinterpret_cast<const float4*>(s->d_shade.ptr);
     ds.groups = s->d_groups.ptr; ds.images = s->d_images.ptr; ds.texels = s->d_texels.ptr;
     std::memcpy(ds.background, s->background, 12);
-    ds.sky = s->sky_size ? s->d_sky.ptr : nullptr; ds.sky_size = s->sky_size; ds.sky_intensity = s->sky_intensity; ds.sky_format = s->sky_format;
+    ds.sky = s->sky_size ? reinterpret_cast<const float4*>(s->d_sky.ptr) : nullptr; ds.sky_size = s->sky_size;
     ds.num_nodes = (uint32_t)nodes.size(); ds.num_tris = (uint32_t)tris.size();
     ds.max_stack = 1; // rows of the per-lane traversal stack the deepest walk of this scene needs
     for (const HostObject& ho : s->objects)

@@ -179,13 +179,12 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES : PT_WAVES_COOP) void r
                     done = true;                  // the next TraceRay would return 0 (PathTracer.cpp:35-36)
                 } else {
                     f3 w;
-                    const uint32_t keyHi = lds_key_hi[slot];
-                    done = !sample_bsdf(h, ray, ior, w, key, keyHi, (uint32_t)bounce);
+                    done = !sample_bsdf(h, ray, ior, w, key, lds_key_hi[slot], (uint32_t)bounce);
                     T = T * w;
                     if (EXT && (rp.flags & kFlagRoulette) && bounce + 1 >= 3 && !done) {
                         // survive with probability q = clamp(max T, 0.05, 1), drawn from slot 7 of this bounce
                         float q = clampf(fmaxf(fmaxf(T.x, T.y), T.z), 0.05f, 1.0f);
-                        if (!(rand01(key, keyHi, (uint32_t)bounce, 7u) < q)) done = true;
+                        if (!(rand01(key, lds_key_hi[slot], (uint32_t)bounce, 7u) < q)) done = true; // read again: not held through the BSDF step
                         else T = T * __fdiv_rn(1.0f, q);
                     }
                     ++bounce;
@@ -411,12 +410,11 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
         }
         if (COUNT) { ++shade_lanes; if (wave_leader()) ++shade_trips; }
         f3 w;
-        const uint32_t keyHi = lds_key_hi[slot];
-        bool done = !sample_bsdf(h, ray, ior, w, key, keyHi, (uint32_t)bounce);
+        bool done = !sample_bsdf(h, ray, ior, w, key, lds_key_hi[slot], (uint32_t)bounce);
         T = T * w;
         if (EXT && (rp.flags & kFlagRoulette) && bounce + 1 >= 3 && !done) {
             float q = clampf(fmaxf(fmaxf(T.x, T.y), T.z), 0.05f, 1.0f);
-            if (!(rand01(key, keyHi, (uint32_t)bounce, 7u) < q)) done = true;
+            if (!(rand01(key, lds_key_hi[slot], (uint32_t)bounce, 7u) < q)) done = true;
             else T = T * __fdiv_rn(1.0f, q);
         }
         ++bounce;

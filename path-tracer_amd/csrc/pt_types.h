@@ -139,13 +139,13 @@ struct DScene {
     const DPbr* groups;
     const DImage* images;
     const uint8_t* texels;
-    float background[3]; int32_t sky_format; // sky texels: 0 = RGBA8 (scaled by sky_intensity), 1 = float4 radiance (rgb, w unused)
+    float background[3]; int32_t pad;
     uint32_t num_nodes, num_tris; // totals over all meshes
     const float4* lds_nodes;  // kLdsNodeBytes per node; present when lds_resident
     uint32_t lds_node_f4;     // their size in float4
     uint32_t lds_resident;    // the LDS nodes and the hot triangles fit kLdsBlockBytes with the stack: traverse them from LDS
-    int32_t sky_size; float sky_intensity; // cubemap miss radiance (no reference counterpart): 0 = constant background
-    const uint32_t* sky;   // 6 faces (+x -x +y -y +z -z) of sky_size^2 texels (one or four words each, see sky_format), row 0 = top
+    int32_t sky_size; int32_t pad2; // cubemap miss radiance (no reference counterpart): 0 = constant background
+    const float4* sky;     // 6 faces (+x -x +y -y +z -z) of sky_size^2 texels of float radiance (rgb, w unused), row 0 = top
 };
 
 // Camera matrices as Camera::CalculateMatrices leaves them (Camera.cpp:22-35), glm column-major.

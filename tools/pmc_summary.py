@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         agg = collections.OrderedDict()
         for r in csv.DictReader(open(f)):
-            if "render_kernel" not in r["Kernel_Name"]:
+            if "render_kernel" not in r["Kernel_Name"] and "render_samples_kernel" not in r["Kernel_Name"]:
                 continue
             k = (r["Dispatch_Id"], r["Grid_Size"], r["VGPR_Count"], r["LDS_Block_Size"])
             agg.setdefault(k, collections.OrderedDict())
