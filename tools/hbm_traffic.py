@@ -26,7 +26,7 @@ bench = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
 name, fetch_kb = first_dispatch(out + "/fetch", "FETCH_SIZE")
 _, write_kb = first_dispatch(out + "/write", "WRITE_SIZE")
 import re
-m = re.search(r"(\d+) spp", bench["config"]["workload"])
+m = re.search(r"(\d+) spp (?:in total|per GPU)", bench["config"]["workload"])
 d = re.search(r"(\d+) bounces", bench["config"]["workload"])
 # FETCH_SIZE tallies every memory-side read request at 64 bytes. Wide coalesced reads (the film) go out as 128-byte
 # requests, so their bytes are twice the reported figure; the 16-byte gathers of a walk through a big mesh go out as 64-byte
