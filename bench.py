@@ -429,10 +429,14 @@ def main():
         if args.config is None and rk.world == 1 and not args.no_others and args.spp is None and args.depth is None:
             others = {}
             for c in (3, 4, 5):
-                r = run_config(rk, c, 2, 1, None, None, "strong", not args.no_cpu, 8.0)
-                keep = ("value", "unit", "ms_per_step", "steps", "warmup", "mrays_per_s", "rays_per_sample", "kernel_ms_per_launch", "config",
-                        "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "speedup_note", "no_roulette")
-                others["config%d" % c] = {k: r[k] for k in keep if k in r}
+                try:
+                    r = run_config(rk, c, 2, 1, None, None, "strong", not args.no_cpu, 8.0)
+                    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "mrays_per_s", "rays_per_sample", "kernel_ms_per_launch", "config",
+                            "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "speedup_note", "no_roulette")
+                    others["config%d" % c] = {k: r[k] for k in keep if k in r}
+                except Exception as e:  # the headline line must come out whatever happens to a side measurement
+                    print("bench: configuration %d failed: %r" % (c, e), file=sys.stderr)
+                    others["config%d" % c] = {"error": repr(e)}
             out["other_configs"] = others
         print(json.dumps(out), flush=True)
     rk.close()
