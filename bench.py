@@ -361,8 +361,14 @@ def _run_workload(rk, ptamd, shard, tmpdir, config, steps, warmup, spp_arg, dept
                 roof["hbm"] = {"achieved": traffic / (kernel_ms * 1e-3) * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": traffic / (kernel_ms * 1e-3) * 1e-9 / HBM_PEAK_GBS}
             out["roofline"] = roof
+            base = cnt = None
             if want_cpu:
-                base, cnt = cpu_baseline(scene, depth, cpu_budget)
+                try:
+                    base, cnt = cpu_baseline(scene, depth, cpu_budget)
+                except Exception as e:  # the GPU measurement stands without its CPU leg
+                    print("bench: CPU baseline failed: %r" % (e,), file=sys.stderr)
+                    out["cpu_baseline"] = {"error": repr(e)}
+            if base is not None:
                 ref_fps = reference_flops(cnt) / max(1, cnt["samples"])
                 roof["reference_equivalent"] = {
                     "flops_per_sample": ref_fps, "tflops": ref_fps * launched / (kernel_ms * 1e-3) * 1e-12,
@@ -371,7 +377,7 @@ def _run_workload(rk, ptamd, shard, tmpdir, config, steps, warmup, spp_arg, dept
                 out["cpu_baseline"] = base
                 if not rr:
                     out["speedup_vs_cpu_baseline"] = value / base["value"]
-            else:
+            elif not want_cpu:
                 out["cpu_baseline"] = None
     film.close()
     pt.close()
@@ -389,7 +395,7 @@ def run_config(rk, config, steps, warmup, spp, depth, scaling, want_cpu, cpu_bud
             out["no_roulette"] = {k: plain[k] for k in ("value", "unit", "mrays_per_s", "rays_per_sample", "kernel_ms_per_launch", "steps")}
             out["no_roulette"]["roofline"] = {k: plain["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "lane_utilisation")}
             out["cpu_baseline"] = plain.get("cpu_baseline")
-            if plain.get("cpu_baseline"):
+            if (plain.get("cpu_baseline") or {}).get("value"):
                 out["speedup_vs_cpu_baseline"] = plain["value"] / plain["cpu_baseline"]["value"]
                 out["speedup_note"] = "no-roulette GPU rate over the CPU reference (which has no roulette): like by like"
     return out
