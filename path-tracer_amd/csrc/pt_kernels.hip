@@ -277,9 +277,13 @@ PT_DEV void add_sample_fx(unsigned long long* acc, f3 c, unsigned long long time
     atomicAdd(&acc[1], to_fixed(c.y) * times);
     atomicAdd(&acc[2], to_fixed(c.z) * times);
 }
-template <bool COUNT, bool EXT>
-__global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DScene sc, DRenderParams rp)
+// LDS_GEOM: the scene's nodes and triangles are staged into LDS (lean traversal); otherwise they are read from global memory
+// by the work-sharing traversals, which every lane of the wave enters together, a lane without a ray as a helper.
+// TILED: the launch covers one rank's interleaved square tiles (ptamd_render_tiles) instead of a rectangle.
+template <bool LDS_GEOM, bool COUNT, bool EXT, bool TILED>
+__global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES_SM : PT_WAVES_COOP) void render_samples_kernel(DScene sc, DRenderParams rp)
 {
+    constexpr bool COOP = !LDS_GEOM;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     StackEntry* stack = reinterpret_cast<StackEntry*>(lds_raw);
     const uint32_t stackBytes = (uint32_t)rp.stack_depth * kBlock * (uint32_t)sizeof(StackEntry);
@@ -289,36 +293,49 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
     float4* cache = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes) + wave * (16 * 5);
     uint32_t* lds_key_hi = reinterpret_cast<uint32_t*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes);
     float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes);
+    Coop coop; // the work-sharing words take the place of the staged geometry: 8 + 4 bytes per lane
+    coop.res = reinterpret_cast<unsigned long long*>(lds_geom);
+    coop.mail = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(lds_geom) + 8 * kBlock);
     const int p0 = lane & 15; // the pixel this lane traces the camera ray of, with three others
     const bool first = lane < 16;
     if (lane == 0) tile.next = 0u;
     if (first) { tile.acc[p0][0] = 0ull; tile.acc[p0][1] = 0ull; tile.acc[p0][2] = 0ull; tile.acc[p0][3] = 0ull; }
-    const Geom geom = stage_geometry<true>(sc, lds_geom); // ends in a workgroup barrier
-    Coop coop; coop.res = nullptr; coop.mail = nullptr;   // the work-sharing traversal is not part of this kernel
+    const Geom geom = stage_geometry<LDS_GEOM>(sc, lds_geom); // with geometry to stage it ends in a workgroup barrier
     // the workgroup covers an 8x8-pixel block, its waves the four 4x4 quadrants
     // Workgroups go to the eight XCDs in turn, and each XCD has its own L2. Of every 64 consecutive 8x8-pixel blocks of the
     // film an XCD takes eight neighbours, so that most blocks which share film cache lines share an L2 (memory-side bytes
     // 130 -> 79 MB per 1080p launch, against 66 MB of film), while every XCD still works all over the film (an eighth of the
     // film per XCD balances worse: 520 against 506 ms).
     const int tileIndex = (int)((blockIdx.x & ~63u) | ((blockIdx.x & 7u) << 3) | ((blockIdx.x >> 3) & 7u));
-    if (tileIndex >= rp.tiles_x * rp.tiles_y) return; // the launch is rounded up to a multiple of 64 blocks
-    const int bx = tileIndex % rp.tiles_x, by = tileIndex / rp.tiles_x;
-    const int tx0 = rp.x0 + bx * 8 + (wave & 1) * 4, ty0 = rp.y0 + by * 8 + (wave >> 1) * 4;
+    int bx0, by0; // the block's first pixel
+    if (TILED) {
+        // one rank's interleaved square tiles: blocks are numbered through the owned tiles one after the other
+        if (tileIndex >= rp.tiles_owned * rp.tile_waves) return; // the launch is rounded up to a multiple of 64 blocks
+        const int owned = tileIndex / rp.tile_waves, sub = tileIndex % rp.tile_waves;
+        const int big = rp.tile_phase + owned * rp.tile_stride;
+        bx0 = (big % rp.tile_cols) * rp.tile_size + (sub % rp.tile_side) * 8; by0 = (big / rp.tile_cols) * rp.tile_size + (sub / rp.tile_side) * 8;
+    } else {
+        if (tileIndex >= rp.tiles_x * rp.tiles_y) return;
+        bx0 = rp.x0 + (tileIndex % rp.tiles_x) * 8; by0 = rp.y0 + (tileIndex / rp.tiles_x) * 8;
+    }
+    const int tx0 = bx0 + (wave & 1) * 4, ty0 = by0 + (wave >> 1) * 4;
     const int W = rp.cam.width;
     const uint32_t seed_hash = pcg_hash(rp.seed);
     const f3 bg = mk3(sc.background[0], sc.background[1], sc.background[2]);
 
     uint32_t nrays = 0, ray_trips = 0, shade_lanes = 0, shade_trips = 0;
     TraversalCounts tc_total; tc_total.nodes = 0; tc_total.tris = 0; tc_total.node_trips = 0; tc_total.tri_trips = 0; tc_total.steal_rounds = 0;
-    auto search = [&](const Ray& r) {
+    uint32_t steal_rounds = 0;
+    auto search = [&](const Ray& r, bool helper) { // helper (work-sharing builds): no ray of its own, takes over others' subtrees
         if (COUNT) {
             TraversalCounts tc;
-            Best b = closest_hit<kBlock, true, false>(sc, geom, r, stack, coop, slot, &tc);
+            Best b = closest_hit<kBlock, true, COOP>(sc, geom, r, stack, coop, slot, &tc, helper);
             tc_total.nodes += tc.nodes; tc_total.tris += tc.tris; tc_total.node_trips += tc.node_trips; tc_total.tri_trips += tc.tri_trips;
+            steal_rounds += tc.steal_rounds;
             if (wave_leader()) ++ray_trips;
             return b;
         }
-        return closest_hit<kBlock, false, false>(sc, geom, r, stack, coop, slot, nullptr);
+        return closest_hit<kBlock, false, COOP>(sc, geom, r, stack, coop, slot, nullptr, helper);
     };
 
     // ---- the camera ray of every pixel of the tile, once (four lanes trace each: coherent, and once per launch)
@@ -330,9 +347,9 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
         const Ray ray = camera_ray(rp.cam, px, py);
         camPos = ray.o;
         const TraversalCounts keep = tc_total;
-        const Best best = search(ray);
-        if (COUNT && !first) tc_total = keep; // one search per pixel in the tallies
-        const bool primaryHit = best.obj >= 0;
+        const Best best = search(ray, COOP && !first); // shared walks: sixteen rays, forty-eight helpers
+        if (COUNT && !first && !COOP) tc_total = keep; // one search per pixel in the tallies (shared walks tally once anyway)
+        const bool primaryHit = best.obj >= 0 && (first || !COOP);
         HitInfo h;
         h.p = mk3(0.f, 0.f, 0.f); h.n = mk3(0.f, 0.f, 1.f); h.frontFace = false; h.albedo = mk3(0.f, 0.f, 0.f); h.roughness = 1.f; h.metallic = 0.f;
         h.emission = mk3(0.f, 0.f, 0.f); h.ior = 1.f; h.transmission = 0.f;
@@ -372,11 +389,17 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
     Ray ray; ray.o = camPos; ray.d = mk3(0.f, 0.f, 1.f);
     uint32_t pi = 0u;  // the pixel (0..15) of the lane's current sample
     bool fresh = true; // the lane's next step is the BSDF sample at a camera-ray hit from the tile's records: no search before it
+    bool idle = false; // shared walks only: the tickets are gone, the lane helps until the wave's last path has ended
     for (;;) {
         bool end = false;
         HitInfo h;
+        Best best;
+        if (COOP) {
+            if (__all(idle)) break;
+            best = search(ray, fresh); // every lane of the wave enters the shared walk; one without a ray helps
+        }
         if (!fresh) {
-            const Best best = search(ray);
+            if (!COOP) best = search(ray, false);
             if (COUNT) ++nrays;
             if (best.obj < 0) {
                 L = L + T * ((EXT && sc.sky_size > 0) ? sky_lookup(sc, ray.d) : bg); // PathTracer.cpp:59-60
@@ -388,9 +411,14 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
             }
             if (end) add_sample_fx(tile.acc[pi], L);
         }
+        if (COOP && idle) continue;
         if (fresh || end) {
             const uint32_t t = atomicAdd(&tile.next, 1u);
-            if (t >= total) break;
+            if (t >= total) {
+                if (!COOP) break;
+                idle = true; fresh = true;
+                continue;
+            }
             uint32_t q;
             if (nvalid == 16u) { q = t >> 4; pi = t & 15u; }
             else { q = nvalid > 1u ? __umulhi(t, magic) : t; pi = tile.list[t - q * nvalid]; }
@@ -426,7 +454,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
     // The film: one wave updates the workgroup's whole 8x8-pixel block, rows of eight pixels (96 contiguous bytes), as the
     // pixel-major kernel does; four waves writing rows of four pixels each cost 1.6 times the memory-side bytes.
     __syncthreads();
-    const int fx = rp.x0 + bx * 8 + (lane & 7), fy = rp.y0 + by * 8 + (lane >> 3);
+    const int fx = bx0 + (lane & 7), fy = by0 + (lane >> 3);
     const bool writes = wave == 0 && fx < rp.x1 && fy < rp.y1;
     if (writes) {
         const SampleTile& src = reinterpret_cast<const SampleTile*>(lds_raw + stackBytes)[((lane >> 5) << 1) | ((lane >> 2) & 1)];
@@ -443,7 +471,7 @@ __global__ __launch_bounds__(kBlock, PT_WAVES_SM) void render_samples_kernel(DSc
         const bool first = writes; // the lanes that stand for a pixel in the sample count
         if (COUNT && rp.counters) {
             unsigned long long c[kNumCounters] = { (first && px < rp.x1 && py < rp.y1) ? rp.spp_count : 0u, nrays, tc_total.nodes, tc_total.tris,
-                                                   ray_trips, tc_total.node_trips, tc_total.tri_trips, shade_lanes, shade_trips, 0u };
+                                                   ray_trips, tc_total.node_trips, tc_total.tri_trips, shade_lanes, shade_trips, steal_rounds };
 #pragma unroll
             for (int k = 0; k < kNumCounters; ++k) {
 #pragma unroll
@@ -546,21 +574,39 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const bool count = rp.counters != nullptr;
     static const bool debug = getenv("PTAMD_DEBUG") != nullptr;
     const bool ext = (rp.flags & kFlagRoulette) != 0 || sc.sky_size > 0;
-    // Many samples per pixel on a scene that is traversed from LDS: the sample-major kernel (see render_samples_kernel).
-    // Fewer than 64 samples leave its waves too short-lived; albedo-only and depth < 2 renders end at the camera ray's hit
-    // anyway. PTAMD_NO_SAMPLE_MAJOR=1 (read per launch) keeps every launch on the pixel-major kernel.
+    // Many samples per pixel: the sample-major kernel (see render_samples_kernel). Fewer than 64 samples leave its waves too
+    // short-lived; albedo-only and depth < 2 renders end at the camera ray's hit anyway. PTAMD_NO_SAMPLE_MAJOR=1 (read per
+    // launch) keeps every launch on the pixel-major kernel.
     const bool noSampleMajor = getenv("PTAMD_NO_SAMPLE_MAJOR") != nullptr;
-    const size_t ldsSamples = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes + geomBytes;
-    if (fits && !tiled && !noSampleMajor && rp.spp_count >= 64u && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only
+    const size_t ldsSamples = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes
+                              + (fits ? geomBytes : (size_t)12 * kBlock);
+    if (!noSampleMajor && rp.spp_count >= 64u && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only
         && ldsSamples <= kLdsBlockBytes) {
-        const int nb = ((rp.tiles_x * rp.tiles_y + 63) / 64) * 64; // one workgroup per 8x8-pixel block, dealt to the XCDs eight neighbours at a time
-#define PT_LAUNCH_S(COUNT, EXT)                                                                                        \
+        const int n8 = tiled ? rp.tiles_owned * rp.tile_waves : rp.tiles_x * rp.tiles_y; // 8x8-pixel blocks, one workgroup each
+        const int nb = ((n8 + 63) / 64) * 64;                                            // dealt to the XCDs eight neighbours at a time
+#define PT_LAUNCH_S(LDSG, COUNT, EXT, TILED)                                                                           \
         do {                                                                                                          \
-            if (debug) fprintf(stderr, "ptamd: render_samples_kernel<%d,%d> stack %d, lds %zu B/block, %d blocks\n", (int)COUNT, (int)EXT, p.stack_depth, ldsSamples, nb); \
-            hipLaunchKernelGGL((render_samples_kernel<COUNT, EXT>), dim3(nb), dim3(kBlock), ldsSamples, stream, sc, p); \
+            if (debug) fprintf(stderr, "ptamd: render_samples_kernel<%d,%d,%d,%d> stack %d, lds %zu B/block, %d blocks\n", (int)LDSG, (int)COUNT, (int)EXT, (int)TILED, p.stack_depth, ldsSamples, nb); \
+            hipLaunchKernelGGL((render_samples_kernel<LDSG, COUNT, EXT, TILED>), dim3(nb), dim3(kBlock), ldsSamples, stream, sc, p); \
         } while (0)
-        if (count) { if (ext) PT_LAUNCH_S(true, true); else PT_LAUNCH_S(true, false); }
-        else { if (ext) PT_LAUNCH_S(false, true); else PT_LAUNCH_S(false, false); }
+        switch ((tiled ? 8 : 0) | (fits ? 4 : 0) | (count ? 2 : 0) | (ext ? 1 : 0)) {
+        case 0: PT_LAUNCH_S(false, false, false, false); break;
+        case 1: PT_LAUNCH_S(false, false, true, false); break;
+        case 2: PT_LAUNCH_S(false, true, false, false); break;
+        case 3: PT_LAUNCH_S(false, true, true, false); break;
+        case 4: PT_LAUNCH_S(true, false, false, false); break;
+        case 5: PT_LAUNCH_S(true, false, true, false); break;
+        case 6: PT_LAUNCH_S(true, true, false, false); break;
+        case 7: PT_LAUNCH_S(true, true, true, false); break;
+        case 8: PT_LAUNCH_S(false, false, false, true); break;
+        case 9: PT_LAUNCH_S(false, false, true, true); break;
+        case 10: PT_LAUNCH_S(false, true, false, true); break;
+        case 11: PT_LAUNCH_S(false, true, true, true); break;
+        case 12: PT_LAUNCH_S(true, false, false, true); break;
+        case 13: PT_LAUNCH_S(true, false, true, true); break;
+        case 14: PT_LAUNCH_S(true, true, false, true); break;
+        default: PT_LAUNCH_S(true, true, true, true); break;
+        }
 #undef PT_LAUNCH_S
         return hipGetLastError();
     }

@@ -1,4 +1,4 @@
-"""The sample-major render kernel (launches of 64 samples per pixel and more on scenes that are traversed from LDS) against
+"""The sample-major render kernel (launches of 64 samples per pixel and more) against
 the pixel-major kernel, which adds a pixel's samples in the reference's order (Film::AddSample, Film.cpp:34-46, called once
 per RayTraceParallel pass, main.cpp:17-28). Both run the same paths -- the random stream is keyed by (pixel, sample) -- so
 ray counts agree and the films differ by float rounding: the sample-major kernel adds the exactly rounded sum of a
@@ -16,18 +16,18 @@ from test_extensions import empty_scene, gradient_faces
 pytestmark = pytest.mark.gpu
 
 
-def both(gpu, scene, spp, depth, spp_begin=0, rect=None, rr=False, seed=5):
+def both(gpu, scene, spp, depth, spp_begin=0, rect=None, rr=False, seed=5, tiles=None):
     """(film of one sample-major launch, film of pixel-major launches of < 64 samples each, stats of both)."""
     pt, cam = gpu.build_scene(scene)
     w, h = scene["film"]
     fs, fp = gpu.Film(w, h), gpu.Film(w, h)
-    gpu.Render(cam, pt, fs, spp, depth, spp_begin=spp_begin, rect=rect, russian_roulette=rr, seed=seed, count=True)
+    gpu.Render(cam, pt, fs, spp, depth, spp_begin=spp_begin, rect=rect, russian_roulette=rr, seed=seed, count=True, tiles=tiles)
     ss = gpu.RenderStats()
     rays = 0
     b = spp_begin
     while b < spp_begin + spp:
         n = min(50, spp_begin + spp - b)
-        gpu.Render(cam, pt, fp, n, depth, spp_begin=b, rect=rect, russian_roulette=rr, seed=seed, count=True)
+        gpu.Render(cam, pt, fp, n, depth, spp_begin=b, rect=rect, russian_roulette=rr, seed=seed, count=True, tiles=tiles)
         rays += gpu.RenderStats()["rays"]
         b += n
     return fs, fp, ss, rays
@@ -85,3 +85,45 @@ def test_sample_major_rect_roulette_and_sky(gpu):
     gpu.Render(cam, pt, f70, 70, 4)
     gpu.Render(cam, pt, f1, 1, 4)
     assert np.allclose(f70.Accum(), 70.0 * f1.Accum(), rtol=2e-7)
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_sample_major_on_meshes_in_global_memory(gpu, monkeypatch, wide):
+    """Meshes too large for LDS are walked from global memory by the whole wave together (binary nodes, or eight-wide
+    quantised nodes): the sample-major kernel's lanes enter every walk with a ray, or as helpers once the tile's tickets are
+    gone. A rectangle launch with ragged edges and one rank's interleaved tiles, with Russian roulette."""
+    monkeypatch.setenv("PTAMD_WIDE_MIN_FACES", "1" if wide else "100000000")
+    w, h = 150, 84
+    scene = presets.mixed("tests/golden/blob.glb", w, h, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
+    info = gpu.build_scene(scene)[0].Info()
+    assert info["lds_resident"] == 0 and (info["wide_nodes"] > 0) == wide
+    fs, fp, ss, rays = both(gpu, scene, 70, 6, spp_begin=3, rect=(2, 1, 147, 83))
+    agree(fs.Accum(), fp.Accum())
+    assert np.array_equal(fs.Samples(), fp.Samples()) and fs.Samples().sum() == 70 * 145 * 82
+    assert ss["samples"] == 70 * 145 * 82 and abs(ss["rays"] - rays) <= 1e-4 * rays, (ss["rays"], rays)
+    assert float(fp.Accum().mean()) > 0.5
+    # one of three ranks' 32-pixel tiles (ragged at the right and bottom edges), with roulette
+    fs, fp, ss, rays = both(gpu, scene, 64, 9, rr=True, tiles=(32, 1, 3))
+    agree(fs.Accum(), fp.Accum())
+    assert np.array_equal(fs.Samples(), fp.Samples()) and 0 < fs.Samples().sum() < 64 * w * h
+    assert abs(ss["rays"] - rays) <= 1e-4 * rays, (ss["rays"], rays)
+    # all three ranks together cover the film once, and equal the rectangle launch bit for bit (the same kernel, the same paths)
+    pt, cam = gpu.build_scene(scene)
+    ft, fr = gpu.Film(w, h), gpu.Film(w, h)
+    for rank in range(3):
+        gpu.Render(cam, pt, ft, 64, 9, russian_roulette=True, seed=5, tiles=(32, rank, 3))
+    gpu.Render(cam, pt, fr, 64, 9, russian_roulette=True, seed=5)
+    assert (ft.Samples() == 64).all()
+    assert np.array_equal(ft.Accum().view(np.uint32), fr.Accum().view(np.uint32))
+
+
+def test_sample_major_tiles_from_lds(gpu):
+    """Tile launches of the LDS-resident build: ranks' tiles add up to the rectangle launch bit for bit."""
+    scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", 100, 54)
+    pt, cam = gpu.build_scene(scene)
+    ft, fr = gpu.Film(100, 54), gpu.Film(100, 54)
+    for rank in range(2):
+        gpu.Render(cam, pt, ft, 80, 8, seed=2, tiles=(16, rank, 2))
+    gpu.Render(cam, pt, fr, 80, 8, seed=2)
+    assert (ft.Samples() == 80).all()
+    assert np.array_equal(ft.Accum().view(np.uint32), fr.Accum().view(np.uint32))
