@@ -179,6 +179,9 @@ typedef struct ptamd_scene_info {
     const void* d_nodes;         /* device addresses of the geometry buffers (identity checks only) */
     const void* d_tris;
     const void* d_shade;
+    uint32_t leading_boxes;      /* unrotated boxes at the head of the object list whose tests share one set of direction
+                                    reciprocals (0 when fewer than two lead the list) */
+    uint32_t reserved;
 } ptamd_scene_info;
 int ptamd_scene_get_info(const ptamd_scene* s, ptamd_scene_info* out);
 

@@ -374,6 +374,9 @@ struct Coop { unsigned long long* res; uint32_t* mail; }; // LDS, one entry per 
 #ifndef PT_SPLIT_GROUPS
 #define PT_SPLIT_GROUPS 1 // the eight-wide walk also hands out parts of current groups
 #endif
+#ifndef PT_LEAD_BOXES
+#define PT_LEAD_BOXES 1 // the leading run of unrotated boxes shares one set of direction reciprocals
+#endif
 #ifndef PT_STEAL_COOL
 #define PT_STEAL_COOL 0  // node trips to wait after a steal round of the two-child walk (1 costs 6 %, 3 costs 16 %: the rounds pay)
 #endif
@@ -713,7 +716,28 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
     TraversalCounts cnt; cnt.nodes = 0; cnt.tris = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.steal_rounds = 0;
     const float kTMin = 1e-4f, kTMax = 1e30f;
     Best best; best.t = kTMax; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
-    for (int i = 0; i < sc.num_objects; ++i) {
+    int i = 0;
+#if PT_LEAD_BOXES
+    // The scene's leading run of unrotated boxes (the walls of a room; DScene::lead_aligned, 0 when shorter than two): their
+    // local ray direction is the world one, so its reciprocals are formed once for the run instead of once per box (three
+    // quarter-rate v_rcp each). Same values, same order of tests as the general loop below.
+    if (sc.lead_aligned > 0) {
+        const float BIG = 1e30f;
+        const f3 inv = mk3(ray.d.x != 0.0f ? frcp(ray.d.x) : -BIG, ray.d.y != 0.0f ? frcp(ray.d.y) : -BIG, ray.d.z != 0.0f ? frcp(ray.d.z) : -BIG);
+        for (; i < sc.lead_aligned; ++i) {
+            const DObject& ob = sc.objects[i];
+            const f3 ro = ray.o - mk3(ob.c[0], ob.c[1], ob.c[2]);
+            const f3 he = mk3(ob.half[0], ob.half[1], ob.half[2]);
+            const f3 t1 = (-he - ro) * inv, t2 = (he - ro) * inv;
+            const float tEntry = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fminf(t1.z, t2.z));
+            const float tExit = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1.z, t2.z));
+            float tHit = tEntry < kTMin ? tExit : tEntry; // Box.cpp:50-54
+            const bool hit = !(tExit < tEntry) & !(tExit < kTMin) & !(tHit < kTMin) & !(tHit > best.t) & (tHit < best.t);
+            if (hit) { best.t = tHit; best.obj = i; }
+        }
+    }
+#endif
+    for (; i < sc.num_objects; ++i) {
         const DObject& ob = sc.objects[i];
         if (ob.kind == KIND_SPHERE) {
             float t = sphere_t(ob, ray, kTMin, best.t);

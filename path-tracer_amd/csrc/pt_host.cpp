@@ -573,6 +573,14 @@ static void append_lds_nodes(const std::vector<DNode>& nodes, std::vector<float>
     }
 }
 
+// DScene::lead_aligned: how many objects at the head of the list are unrotated boxes (fewer than two count as none).
+static int32_t leading_aligned_boxes(const std::vector<DObject>& objects)
+{
+    size_t n = 0;
+    while (n < objects.size() && objects[n].kind == KIND_BOX && objects[n].aligned) ++n;
+    return n >= 2 ? (int32_t)n : 0;
+}
+
 static int commit_scene(ptamd_scene* s);
 int ptamd_scene_commit(ptamd_scene* s)
 {
@@ -638,6 +646,7 @@ static int commit_scene(ptamd_scene* s)
                 if (changed[m]) { PT_HIP(hipMemcpyAsync(s->d_meshes.ptr + m, &s->h_meshes[m], sizeof(DMesh), hipMemcpyHostToDevice, g_stream)); ++s->row_updates; }
         }
         PT_HIP(hipStreamSynchronize(g_stream)); // the copies read host rows that the next edit may change
+        s->dscene.lead_aligned = leading_aligned_boxes(s->h_objects); // a rotation edit can end or extend the run
         s->committed = true;
         s->last_commit_seconds = seconds_since(t_begin);
         return PTAMD_OK;
@@ -821,6 +830,7 @@ static int commit_scene(ptamd_scene* s)
     ds.max_stack = 1; // rows of the per-lane traversal stack the deepest walk of this scene needs
     for (const HostObject& ho : s->objects)
         if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, uses_wide(*ho.mesh) ? 2 * ho.mesh->bvh.wide_depth : ho.mesh->bvh.depth);
+    ds.lead_aligned = leading_aligned_boxes(objects);
     s->h_objects = std::move(objects); s->h_meshes = std::move(meshes); s->h_groups = std::move(groups);
     s->edits.assign(s->objects.size(), 0);
     s->structure_dirty = false;
@@ -837,6 +847,7 @@ int ptamd_scene_get_info(const ptamd_scene* s, ptamd_scene_info* out)
     out->objects = (uint32_t)s->objects.size(); out->meshes = (uint32_t)s->h_meshes.size();
     out->triangles = s->dscene.num_tris; out->nodes = (uint32_t)s->d_nodes.count; out->wide_nodes = (uint32_t)s->d_wide.count;
     out->lds_resident = s->dscene.lds_resident;
+    out->leading_boxes = (uint32_t)s->dscene.lead_aligned;
     out->geometry_uploads = s->geometry_uploads; out->row_updates = s->row_updates;
     out->last_commit_seconds = s->last_commit_seconds; out->last_bvh_seconds = s->last_bvh_seconds;
     out->d_nodes = s->d_wide.count ? (const void*)s->d_wide.ptr : (const void*)s->d_nodes.ptr; out->d_tris = s->d_tris.ptr; out->d_shade = s->d_shade.ptr;

@@ -139,7 +139,8 @@ struct DScene {
     const DPbr* groups;
     const DImage* images;
     const uint8_t* texels;
-    float background[3]; int32_t pad;
+    float background[3];
+    int32_t lead_aligned;     // objects [0, lead_aligned) are all unrotated boxes (DObject::aligned); 0 when fewer than two lead the list
     uint32_t num_nodes, num_tris; // totals over all meshes
     const float4* lds_nodes;  // kLdsNodeBytes per node; present when lds_resident
     uint32_t lds_node_f4;     // their size in float4

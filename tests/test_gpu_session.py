@@ -102,3 +102,35 @@ def test_counting_renders_of_two_scenes_do_not_share_tallies(gpu):
     a.close()
     with pytest.raises(gpu.PtamdError, match="PTAMD_FLAG_COUNT"):
         gpu.RenderStats()
+
+
+def test_leading_run_of_unrotated_boxes_changes_no_image_and_follows_edits(gpu):
+    """The unrotated boxes at the head of the object list are tested with one shared set of direction reciprocals
+    (closest_hit in pt_device.h): the same values in the same order as the per-box test (Box.cpp:16-54), so the film is
+    bit-identical to that of the same scene behind a leading sphere that no ray meets (which ends the run before it
+    starts), in both render kernels. A rotation edit shortens or restores the run at the next commit."""
+    scene = presets.box_cornell(96, 64)
+    pt, cam = gpu.build_scene(scene)
+    assert pt.Info()["leading_boxes"] == 7  # six walls and the light; the two inner blocks are rotated
+    behind = dict(scene, objects=[{"type": "sphere", "pos": (0.0, -500.0, 0.0), "radius": 0.25, "mat": scene["objects"][0]["mat"]}] + scene["objects"])
+    pt0, cam0 = gpu.build_scene(behind)
+    assert pt0.Info()["leading_boxes"] == 0
+    for spp in (3, 64):  # pixel-major and sample-major launches
+        a, b = gpu.Film(96, 64), gpu.Film(96, 64)
+        gpu.Render(cam, pt, a, spp, 6, seed=5)
+        gpu.Render(cam0, pt0, b, spp, 6, seed=5)
+        assert np.array_equal(a.Accum().view(np.uint32), b.Accum().view(np.uint32))
+    hits = pt.ClosestHits(np.load("tests/golden/box_cornell.npz")["rays"])
+    hits0 = pt0.ClosestHits(np.load("tests/golden/box_cornell.npz")["rays"])
+    assert np.array_equal(hits.view(np.uint32), hits0.view(np.uint32))
+    # an edit that rotates the second wall ends the run after the first box (one box is no run); undoing it restores it
+    first = pt.GetRayObjects()[1]
+    first.SetRotation((0.0, 0.0, 3.0)); pt.Commit()
+    assert pt.Info()["leading_boxes"] == 0
+    first.SetRotation((0.0, 0.0, 0.0)); pt.Commit()
+    assert pt.Info()["leading_boxes"] == 7
+    c = gpu.Film(96, 64)
+    gpu.Render(cam, pt, c, 3, 6, seed=5)
+    d = gpu.Film(96, 64)
+    gpu.Render(cam0, pt0, d, 3, 6, seed=5)
+    assert np.array_equal(c.Accum().view(np.uint32), d.Accum().view(np.uint32))
