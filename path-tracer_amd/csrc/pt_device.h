@@ -257,7 +257,7 @@ PT_DEV int hit_triangle(const float4* tris, int slot, bool quad, f3 o, f3 d, flo
 }
 
 // Where the traversal reads BVH nodes and hot triangles (3 float4 each) from: the global arrays of the scene
-// (DNode, 4 float4 per node, read by the work-sharing traversal), or the copy that the workgroup staged into LDS
+// (DSignNode, 7 float4 per node, read by the work-sharing traversal), or the copy that the workgroup staged into LDS
 // for a scene of a few KB (nodes in the LDS format of kLdsNodeBytes, read by mesh_traverse).
 struct Geom { const float4* nodes; const float4* tris; };
 
@@ -392,7 +392,7 @@ template <int BLOCK, bool COUNT>
 PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& me, bool valid, f3 o, f3 d, float tMinObj, float& closestT,
                          StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts& cnt)
 {
-    const float4* __restrict__ nodes = geom.nodes + (size_t)me.node_base * 4;
+    const char* __restrict__ nodes = reinterpret_cast<const char*>(geom.nodes) + (size_t)me.node_base * sizeof(DSignNode);
     const float4* __restrict__ tris = geom.tris + (size_t)me.tri_base * 3;
     const float BIG = 1e30f;
     const int lane = slot & 63, waveBase = slot & ~63;
@@ -427,20 +427,19 @@ PT_DEV int mesh_traverse_coop(const DScene& sc, const Geom& geom, const DMesh& m
         if (nInner > 0 && (nInner >= nLeaf || nLeaf < leafMin)) {
             if (isInner) {
                 if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
-                const float4* n = nodes + (size_t)cur * 4;
-                float4 a = n[0], b = n[1], c = n[2], r = n[3];
-                float lx0 = fmaf(a.x, inv.x, -oi.x), lx1 = fmaf(a.w, inv.x, -oi.x);
-                float ly0 = fmaf(a.y, inv.y, -oi.y), ly1 = fmaf(b.x, inv.y, -oi.y);
-                float lz0 = fmaf(a.z, inv.z, -oi.z), lz1 = fmaf(b.y, inv.z, -oi.z);
-                float rx0 = fmaf(b.z, inv.x, -oi.x), rx1 = fmaf(c.y, inv.x, -oi.x);
-                float ry0 = fmaf(b.w, inv.y, -oi.y), ry1 = fmaf(c.z, inv.y, -oi.y);
-                float rz0 = fmaf(c.x, inv.z, -oi.z), rz1 = fmaf(c.w, inv.z, -oi.z);
-                float lmin = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), 0.0f));
-                float lmax = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), bound));
-                float rmin = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), 0.0f));
-                float rmax = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), bound));
+                // DSignNode: per axis the 16 bytes that start with the planes this task's ray enters through (the sign bit of
+                // the reciprocal direction picks the half: a thief's ray is not the lane's own, so it is taken per visit)
+                const char* n = nodes + (size_t)cur * sizeof(DSignNode);
+                const float4 x = *reinterpret_cast<const float4*>(n + ((__float_as_uint(inv.x) >> 27) & 16u));      // l.near, r.near, l.far, r.far
+                const float4 y = *reinterpret_cast<const float4*>(n + 32 + ((__float_as_uint(inv.y) >> 27) & 16u));
+                const float4 z = *reinterpret_cast<const float4*>(n + 64 + ((__float_as_uint(inv.z) >> 27) & 16u));
+                const int2 ch = *reinterpret_cast<const int2*>(n + 96);
+                float lmin = fmaxf(fmaxf(fmaf(x.x, inv.x, -oi.x), fmaf(y.x, inv.y, -oi.y)), fmaxf(fmaf(z.x, inv.z, -oi.z), 0.0f));
+                float lmax = fminf(fminf(fmaf(x.z, inv.x, -oi.x), fmaf(y.z, inv.y, -oi.y)), fminf(fmaf(z.z, inv.z, -oi.z), bound));
+                float rmin = fmaxf(fmaxf(fmaf(x.y, inv.x, -oi.x), fmaf(y.y, inv.y, -oi.y)), fmaxf(fmaf(z.y, inv.z, -oi.z), 0.0f));
+                float rmax = fminf(fminf(fmaf(x.w, inv.x, -oi.x), fmaf(y.w, inv.y, -oi.y)), fminf(fmaf(z.w, inv.z, -oi.z), bound));
                 bool hl = lmax >= lmin, hr = rmax >= rmin;
-                int left = __float_as_int(r.x), right = __float_as_int(r.y);
+                int left = ch.x, right = ch.y;
                 if (hl && hr) {
                     bool leftNear = lmin < rmin; // Mesh.cpp:143
                     stack[sp * BLOCK + slot] = (uint32_t)(leftNear ? right : left);
@@ -734,6 +733,26 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
             float tHit = tEntry < kTMin ? tExit : tEntry; // Box.cpp:50-54
             const bool hit = !(tExit < tEntry) & !(tExit < kTMin) & !(tHit < kTMin) & !(tHit > best.t) & (tHit < best.t);
             if (hit) { best.t = tHit; best.obj = i; }
+        }
+    }
+    // The spheres that follow that run directly (DScene::sphere_run, 0 when fewer than two): a = d . d and its reciprocal
+    // do not depend on the sphere (Sphere.cpp:36,46-48) and are formed once for the run.
+    if (sc.sphere_run > 0) {
+        const float a = dot(ray.d, ray.d), ia = frcp(a);
+        for (const int end = i + sc.sphere_run; i < end; ++i) {
+            const DObject& ob = sc.objects[i];
+            const f3 oc = ray.o - mk3(ob.c[0], ob.c[1], ob.c[2]);
+            const float h = dot(oc, ray.d);
+            const float c = dot(oc, oc) - ob.radius * ob.radius;
+            const float disc = h * h - a * c;
+            if (disc < 0.0f) continue;
+            const float sq = fsqrt(disc);
+            float t = (-h - sq) * ia;
+            if (t < kTMin || t > best.t) {
+                t = (-h + sq) * ia;
+                if (t < kTMin || t > best.t) continue;
+            }
+            if (t >= 0.0f && t < best.t) { best.t = t; best.obj = i; }
         }
     }
 #endif

@@ -100,7 +100,7 @@ struct ptamd_scene {
     uint64_t geometry_uploads = 0, row_updates = 0;
     double last_commit_seconds = 0.0, last_bvh_seconds = 0.0;
     DevBuf<DObject> d_objects; DevBuf<DMesh> d_meshes; DevBuf<DMaterial> d_materials;
-    DevBuf<DNode> d_nodes; DevBuf<DWideNode> d_wide; DevBuf<float> d_lds_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
+    DevBuf<DSignNode> d_nodes; DevBuf<DWideNode> d_wide; DevBuf<float> d_lds_nodes; DevBuf<DTri> d_tris; DevBuf<DShade> d_shade; DevBuf<DPbr> d_groups;
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
     DevBuf<float> d_sky; int sky_size = 0;
     unsigned long long* d_counters = nullptr; // this scene's PTAMD_FLAG_COUNT tallies (allocated by its first counting render)
@@ -581,6 +581,30 @@ static int32_t leading_aligned_boxes(const std::vector<DObject>& objects)
     return n >= 2 ? (int32_t)n : 0;
 }
 
+// DScene::sphere_run: how many spheres follow the leading boxes directly (fewer than two count as none).
+static int32_t sphere_run_after(const std::vector<DObject>& objects, int32_t lead)
+{
+    size_t n = (size_t)lead;
+    while (n < objects.size() && objects[n].kind == KIND_SPHERE) ++n;
+    return n - (size_t)lead >= 2 ? (int32_t)(n - (size_t)lead) : 0;
+}
+
+// Appends one DSignNode per DNode (the upload format of the two-child trees, pt_types.h).
+static void append_sign_nodes(const std::vector<DNode>& nodes, std::vector<DSignNode>& out)
+{
+    for (const DNode& n : nodes) {
+        const float lmin[3] = { n.lmin[0], n.lmin[1], n.lmin[2] }, lmax[3] = { n.lmax0, n.lmax12[0], n.lmax12[1] };
+        const float rmin[3] = { n.rmin01[0], n.rmin01[1], n.rmin2 }, rmax[3] = { n.rmax[0], n.rmax[1], n.rmax[2] };
+        DSignNode d; std::memset(&d, 0, sizeof d);
+        for (int k = 0; k < 3; ++k) {
+            const float both[8] = { lmin[k], rmin[k], lmax[k], rmax[k], lmax[k], rmax[k], lmin[k], rmin[k] };
+            std::memcpy(d.axis[k], both, sizeof both);
+        }
+        d.left = n.left; d.right = n.right;
+        out.push_back(d);
+    }
+}
+
 static int commit_scene(ptamd_scene* s);
 int ptamd_scene_commit(ptamd_scene* s)
 {
@@ -647,6 +671,7 @@ static int commit_scene(ptamd_scene* s)
         }
         PT_HIP(hipStreamSynchronize(g_stream)); // the copies read host rows that the next edit may change
         s->dscene.lead_aligned = leading_aligned_boxes(s->h_objects); // a rotation edit can end or extend the run
+        s->dscene.sphere_run = sphere_run_after(s->h_objects, s->dscene.lead_aligned);
         s->committed = true;
         s->last_commit_seconds = seconds_since(t_begin);
         return PTAMD_OK;
@@ -655,7 +680,7 @@ static int commit_scene(ptamd_scene* s)
     double bvhSeconds = 0.0;
     const int maxDepth = max_stack_depth();
     std::vector<DObject> objects; std::vector<DMesh> meshes; std::vector<DMaterial> materials;
-    std::vector<DNode> nodes; std::vector<DTri> tris; std::vector<DShade> shade; std::vector<DPbr> groups;
+    std::vector<DSignNode> nodes; std::vector<DTri> tris; std::vector<DShade> shade; std::vector<DPbr> groups;
     std::vector<DImage> images; std::vector<uint8_t> texels;
     ptamd_material defMat; ptamd_material_default(&defMat);
     materials.push_back(to_dmaterial(defMat)); // slot 0: Material{} (faces without a material group, Mesh.cpp:242-246)
@@ -730,7 +755,7 @@ static int commit_scene(ptamd_scene* s)
                     wideNodes.insert(wideNodes.end(), hm.bvh.wide.begin(), hm.bvh.wide.end());
                 } else {
                     ms.node_base = (uint32_t)nodes.size();
-                    nodes.insert(nodes.end(), hm.bvh.nodes.begin(), hm.bvh.nodes.end());
+                    append_sign_nodes(hm.bvh.nodes, nodes);
                     if (ldsResident) append_lds_nodes(hm.bvh.nodes, ldsNodes);
                 }
                 std::vector<int32_t> faceMaterial; // per group: constant material slot, or -1 when the group samples images
@@ -831,6 +856,7 @@ static int commit_scene(ptamd_scene* s)
     for (const HostObject& ho : s->objects)
         if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, uses_wide(*ho.mesh) ? 2 * ho.mesh->bvh.wide_depth : ho.mesh->bvh.depth);
     ds.lead_aligned = leading_aligned_boxes(objects);
+    ds.sphere_run = sphere_run_after(objects, ds.lead_aligned);
     s->h_objects = std::move(objects); s->h_meshes = std::move(meshes); s->h_groups = std::move(groups);
     s->edits.assign(s->objects.size(), 0);
     s->structure_dirty = false;

@@ -3,8 +3,9 @@
 // Everything the kernels read is one of:
 //   * a wave-uniform table (objects, mesh instances, materials, PBR groups): read through scalar
 //     loads, a few hundred bytes per scene;
-//   * per-mesh BVH nodes (64 B, both child boxes in the parent) and hot triangles (48 B: v0,e1,e2),
-//     stored as float4 so that every per-lane fetch is a 16-byte load;
+//   * per-mesh BVH nodes (both child boxes in the parent: 112 B with the planes in both ray orders, or 80 B with eight
+//     quantised children) and hot triangles (48 B, plane form), stored as float4 so that every per-lane fetch is a
+//     16-byte load;
 //   * cold per-triangle shading records (112 B) touched once per ray at the closest hit;
 //   * the film (12 B accum + 4 B count per pixel), read and written once per launch.
 #pragma once
@@ -37,7 +38,7 @@ struct DObject {
 struct DMesh {
     float minv[12];   // minv[4*r + c] = Minv[c][r] (glm column-major), r = 0..2, c = 0..3
     float m[12];      // same for M
-    uint32_t node_base;   // index of this mesh's root node in the node array (in 64-B nodes)
+    uint32_t node_base;   // index of this mesh's first node in the node array
     uint32_t tri_base;    // index of its first hot triangle (in 48-B records)
     uint32_t group_base;  // index of its first PBR group
     uint32_t image_base;  // index of its first image
@@ -50,7 +51,7 @@ struct DMesh {
     uint32_t pad;
 };
 
-// BVH2 node holding both children's boxes. Child reference: >= 0 -> node index (relative to node_base);
+// BVH2 node holding both children's boxes, as the tree builder emits it (uploaded as DSignNode). Child reference: >= 0 -> node index (relative to node_base);
 // < 0 -> leaf: ~ref = (first_slot << 6) | (quad_mask << 2) | (primitives - 1), slots relative to tri_base; bit i of
 // quad_mask: primitive i is a quad (two adjacent slots tested through the first one's record).
 struct DNode {
@@ -59,6 +60,18 @@ struct DNode {
     float rmin2; float rmax[3];     // f4 2: r.min.z, r.max.xyz
     int32_t left, right; int32_t pad[2]; // f4 3
 };
+
+// The form in which the two-child nodes are uploaded for the work-sharing walk over global memory (mesh_traverse_coop),
+// one per DNode in the same order. Per axis eight floats [l.min, r.min, l.max, r.max | l.max, r.max, l.min, r.min]
+// (l, r: the two children's boxes): a ray that travels along +axis reads the first four with one 16-byte load, one that
+// travels along -axis the second four, and either way gets (l.near, r.near, l.far, r.far) in its own order, so the slab
+// test needs no per-axis min/max (14 half-rate instructions fewer per visit) and computes the same values
+// (a * inv - o * inv is monotonic in a). Child references as in DNode.
+struct DSignNode {
+    float axis[3][8];
+    int32_t left, right; int32_t pad[2];
+};
+static_assert(sizeof(DSignNode) == 112, "DSignNode is 7 float4");
 
 // Eight-wide node with quantised child boxes for meshes that are read from global memory, where a ray's cost is the
 // bytes it pulls through L2 (a DNode spends 32 bytes per child box, this one 10). Child boxes are stored on a grid of
@@ -132,7 +145,7 @@ struct DScene {
     const DObject* objects; int32_t num_objects; int32_t max_stack;
     const DMesh* meshes;
     const DMaterial* materials;
-    const float4* nodes;   // DNode as 4 float4
+    const float4* nodes;   // DSignNode as 7 float4
     const float4* wide_nodes; // DWideNode as 5 float4 (meshes with flag bit 2)
     const float4* tris;    // DTri as 3 float4
     const float4* shade;   // DShade as 7 float4
@@ -145,7 +158,8 @@ struct DScene {
     const float4* lds_nodes;  // kLdsNodeBytes per node; present when lds_resident
     uint32_t lds_node_f4;     // their size in float4
     uint32_t lds_resident;    // the LDS nodes and the hot triangles fit kLdsBlockBytes with the stack: traverse them from LDS
-    int32_t sky_size; int32_t pad2; // cubemap miss radiance (no reference counterpart): 0 = constant background
+    int32_t sky_size;      // cubemap miss radiance (no reference counterpart): 0 = constant background
+    int32_t sphere_run;    // objects [lead_aligned, lead_aligned + sphere_run) are all spheres; 0 when fewer than two follow the boxes
     const float4* sky;     // 6 faces (+x -x +y -y +z -z) of sky_size^2 texels of float radiance (rgb, w unused), row 0 = top
 };
 
