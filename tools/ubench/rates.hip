@@ -44,6 +44,21 @@ KERNEL(k_cvt_ub1, "v_cvt_f32_ubyte1 %0, %0")
 KERNEL(k_cvt_f16, "v_cvt_f32_f16 %0, %0")
 KERNEL(k_bfe, "v_bfe_u32 %0, %0, 8, 8")
 KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %2")
+KERNEL(k_cvt_ub0, "v_cvt_f32_ubyte0 %0, %0")
+KERNEL(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
+KERNEL(k_lshl_or, "v_lshl_or_b32 %0, %0, 8, %1")
+KERNEL(k_bfi, "v_bfi_b32 %0, %1, %0, %2")
+KERNEL(k_sqrt, "v_sqrt_f32 %0, %0")
+KERNEL(k_rsq, "v_rsq_f32 %0, %0")
+KERNEL(k_sin, "v_sin_f32 %0, %0")
+KERNEL(k_cvt_u32, "v_cvt_f32_u32 %0, %0")
+KERNEL(k_sub, "v_sub_f32 %0, %0, %1")
+KERNEL(k_cnd_e64, "v_cndmask_b32_e64 %0, %0, %1, s[36:37]")
+KERNEL(k_cmp_cnd, "v_cmp_ge_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc")
+KERNEL(k_cmp_e64_cnd, "v_cmp_ge_f32_e64 s[36:37], %0, %1\n v_cndmask_b32_e64 %0, %0, %2, s[36:37]")
+KERNEL(k_cmp_sgpr, "v_cmp_ge_f32_e64 s[36:37], %0, %1")
+KERNEL(k_lshr, "v_lshrrev_b32 %0, 3, %0")
+KERNEL(k_fmac, "v_fmac_f32 %0, %1, %2")
 
 template <class K> static void run(const char* name, K kernel, float* out)
 {
@@ -65,5 +80,6 @@ int main()
 #define RUN(k) run(#k, k, out)
     RUN(k_fma); RUN(k_mul); RUN(k_add); RUN(k_max); RUN(k_min); RUN(k_max3); RUN(k_min3); RUN(k_med3); RUN(k_imax); RUN(k_imax3); RUN(k_umin);
     RUN(k_iadd); RUN(k_and); RUN(k_cndmask); RUN(k_cmp); RUN(k_rcp); RUN(k_mul24); RUN(k_mullo); RUN(k_lshladd); RUN(k_mov); RUN(k_mix_lo); RUN(k_mix_hi); RUN(k_cvt_ub1); RUN(k_cvt_f16); RUN(k_bfe); RUN(k_perm);
+    RUN(k_cvt_ub0); RUN(k_and_or); RUN(k_lshl_or); RUN(k_bfi); RUN(k_sqrt); RUN(k_rsq); RUN(k_sin); RUN(k_cvt_u32); RUN(k_sub); RUN(k_cnd_e64); RUN(k_cmp_cnd); RUN(k_cmp_e64_cnd); RUN(k_cmp_sgpr); RUN(k_lshr); RUN(k_fmac);
     return 0;
 }
