@@ -274,9 +274,21 @@ struct TraversalCounts { uint32_t nodes, tris, node_trips, tri_trips, steal_roun
 PT_DEV bool wave_leader() { return (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1; }
 typedef uint32_t StackEntry;
 
-template <int BLOCK, bool COUNT>
+// A search with a budget (sample-major kernel on LDS-resident scenes). A wave pays for the longest of its 64 walks: 26 node
+// trips for 9 visits per lane on the mesh Cornell. With a budget the wave leaves the walk after `trips` node trips; a lane
+// whose walk is not finished parks its traversal state (six words in LDS; its stack column stays where it is) and goes on
+// in the wave's next search, beside the new rays of the lanes that finished, which are shaded in between. The walk of a
+// lane is the same sequence of steps either way, so its closest hit (and which of two equal hits it keeps) does not change.
+struct WalkBudget {
+    uint32_t* park;   // LDS, [3][BLOCK]: node reference with the stack height above it, closest distance, triangle
+    uint32_t trips;   // node trips the wave may spend in one search (wave-uniform)
+    bool resume;      // in: the lane goes on with its parked walk
+    bool unfinished;  // out: the lane's walk is parked again
+};
+
+template <int BLOCK, bool COUNT, bool BUDGET = false>
 PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f3 o, f3 d, float tMinObj, float& closestT,
-                          int& bestTri, float& bu, float& bv, StackEntry* __restrict__ stack, int slot, TraversalCounts& cnt)
+                          int& bestTri, float& bu, float& bv, StackEntry* __restrict__ stack, int slot, TraversalCounts& cnt, WalkBudget* wb = nullptr)
 {
     const char* __restrict__ nodes = reinterpret_cast<const char*>(geom.nodes) + (size_t)me.node_base * kLdsNodeBytes;
     const float4* __restrict__ tris = geom.tris + (size_t)me.tri_base * 3;
@@ -290,49 +302,87 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
     constexpr int kDone = 0x7fffffff; // never a valid node reference
     int sp = 0;
     int cur = me.root >= 0 ? me.root * (int)kLdsNodeBytes : me.root; // inner nodes: byte offset
+    if (BUDGET && wb->resume) {
+        const uint32_t* pk = wb->park + slot;
+        const uint32_t w = pk[0];
+        cur = (int)(w << 5) >> 5; sp = (int)(w >> 27); closestT = __uint_as_float(pk[BLOCK]); bestTri = (int)pk[2 * BLOCK];
+    }
     auto pop = [&]() {
         if (sp > 0) { --sp; cur = (int)stack[sp * BLOCK + slot]; } else cur = kDone;
     };
-    while (cur != kDone) {
-        while ((uint32_t)cur < (uint32_t)kDone) { // inner node
-            if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
-            const float4 x = *reinterpret_cast<const float4*>(ax + cur); // l.near, r.near, l.far, r.far
-            const float4 y = *reinterpret_cast<const float4*>(ay + cur);
-            const float4 z = *reinterpret_cast<const float4*>(az + cur);
-            const int2 ch = *reinterpret_cast<const int2*>(nodes + cur + 96);
-            float lmin = fmaxf(fmaxf(fmaf(x.x, inv.x, -oi.x), fmaf(y.x, inv.y, -oi.y)), fmaxf(fmaf(z.x, inv.z, -oi.z), 0.0f));
-            float lmax = min_raw(min3_raw(fmaf(x.z, inv.x, -oi.x), fmaf(y.z, inv.y, -oi.y), fmaf(z.z, inv.z, -oi.z)), closestT);
-            float rmin = fmaxf(fmaxf(fmaf(x.y, inv.x, -oi.x), fmaf(y.y, inv.y, -oi.y)), fmaxf(fmaf(z.y, inv.z, -oi.z), 0.0f));
-            float rmax = min_raw(min3_raw(fmaf(x.w, inv.x, -oi.x), fmaf(y.w, inv.y, -oi.y), fmaf(z.w, inv.z, -oi.z)), closestT);
-            bool hl = lmax >= lmin, hr = rmax >= rmin;
-            const int left = ch.x, right = ch.y;
-            if (hl && hr) {
-                bool leftNear = lmin < rmin; // Mesh.cpp:143
-                stack[sp * BLOCK + slot] = (uint32_t)(leftNear ? right : left);
-                ++sp;
-                cur = leftNear ? left : right;
-            } else if (hl || hr) {
-                cur = hl ? left : right;
-            } else {
-                pop();
-            }
-        }
-        if (cur < 0) { // leaf: 1..4 primitives (the builder makes at most 2); ~ref = first_slot << 6 | quad_mask << 2 | (primitives - 1)
-            uint32_t code = ~(uint32_t)cur;
-            uint32_t slotIdx = code >> 6, mask = (code >> 2) & 15u, prims = (code & 3u) + 1u;
-            for (uint32_t i = 0; i < prims; ++i, mask >>= 1) {
-                if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
-                const bool quad = (mask & 1u) != 0u;
-                const uint32_t rec = slotIdx;
-                slotIdx += quad ? 2u : 1u;
-                float t, u, v, dn;
-                // (records staged in LDS: their index fits 24 bits, and a 24-bit multiply runs at the full rate)
-                if (!tri_test<false>(tris + __umul24(rec, 3u), o, d, tMinObj, closestT, quad, t, u, v, dn)) continue; // Mesh.cpp:104
-                const int tri = hit_triangle(tris, (int)rec, quad, o, d, u, v, dn);
-                if ((me.flags & 1u) && !alpha_pass(sc, me, tri, u, v)) continue; // Mesh.cpp:106-125
-                closestT = t; bestTri = with_side(tri, dn); bu = u; bv = v;
-            }
+    auto node_step = [&]() {
+        if (COUNT) { ++cnt.nodes; if (wave_leader()) ++cnt.node_trips; }
+        const float4 x = *reinterpret_cast<const float4*>(ax + cur); // l.near, r.near, l.far, r.far
+        const float4 y = *reinterpret_cast<const float4*>(ay + cur);
+        const float4 z = *reinterpret_cast<const float4*>(az + cur);
+        const int2 ch = *reinterpret_cast<const int2*>(nodes + cur + 96);
+        float lmin = fmaxf(fmaxf(fmaf(x.x, inv.x, -oi.x), fmaf(y.x, inv.y, -oi.y)), fmaxf(fmaf(z.x, inv.z, -oi.z), 0.0f));
+        float lmax = min_raw(min3_raw(fmaf(x.z, inv.x, -oi.x), fmaf(y.z, inv.y, -oi.y), fmaf(z.z, inv.z, -oi.z)), closestT);
+        float rmin = fmaxf(fmaxf(fmaf(x.y, inv.x, -oi.x), fmaf(y.y, inv.y, -oi.y)), fmaxf(fmaf(z.y, inv.z, -oi.z), 0.0f));
+        float rmax = min_raw(min3_raw(fmaf(x.w, inv.x, -oi.x), fmaf(y.w, inv.y, -oi.y), fmaf(z.w, inv.z, -oi.z)), closestT);
+        bool hl = lmax >= lmin, hr = rmax >= rmin;
+        const int left = ch.x, right = ch.y;
+        if (hl && hr) {
+            bool leftNear = lmin < rmin; // Mesh.cpp:143
+            stack[sp * BLOCK + slot] = (uint32_t)(leftNear ? right : left);
+            ++sp;
+            cur = leftNear ? left : right;
+        } else if (hl || hr) {
+            cur = hl ? left : right;
+        } else {
             pop();
+        }
+    };
+    auto leaf_pass = [&]() { // leaf: 1..4 primitives (the builder makes at most 2); ~ref = first_slot << 6 | quad_mask << 2 | (primitives - 1)
+        uint32_t code = ~(uint32_t)cur;
+        uint32_t slotIdx = code >> 6, mask = (code >> 2) & 15u, prims = (code & 3u) + 1u;
+        for (uint32_t i = 0; i < prims; ++i, mask >>= 1) {
+            if (COUNT) { ++cnt.tris; if (wave_leader()) ++cnt.tri_trips; }
+            const bool quad = (mask & 1u) != 0u;
+            const uint32_t rec = slotIdx;
+            slotIdx += quad ? 2u : 1u;
+            float t, u, v, dn;
+            // (records staged in LDS: their index fits 24 bits, and a 24-bit multiply runs at the full rate)
+            if (!tri_test<false>(tris + __umul24(rec, 3u), o, d, tMinObj, closestT, quad, t, u, v, dn)) continue; // Mesh.cpp:104
+            const int tri = hit_triangle(tris, (int)rec, quad, o, d, u, v, dn);
+            if ((me.flags & 1u) && !alpha_pass(sc, me, tri, u, v)) continue; // Mesh.cpp:106-125
+            closestT = t; bestTri = with_side(tri, dn);
+            if (!BUDGET) { bu = u; bv = v; } // (a walk with a budget rebuilds them at its end: two registers fewer through the loops)
+        }
+        pop();
+    };
+    if (!BUDGET) {
+        while (cur != kDone) {
+            while ((uint32_t)cur < (uint32_t)kDone) node_step(); // inner node
+            if (cur < 0) leaf_pass();
+        }
+    } else {
+        // The same two phases with wave-uniform loop conditions, so that the trips are counted once per wave (a counter in
+        // a loop that lanes leave one by one would be a counter per lane).
+        uint32_t left = wb->trips;
+        for (;;) {
+            bool go = (uint32_t)cur < (uint32_t)kDone && left != 0u;
+            if (__any(go)) {
+                do {
+                    --left;
+                    if (go) node_step();
+                    go = (uint32_t)cur < (uint32_t)kDone && left != 0u;
+                } while (__any(go));
+            }
+            if (cur < 0) leaf_pass();
+            if (!__any(cur != kDone && left != 0u)) break;
+        }
+        wb->unfinished = cur != kDone;
+        if (wb->unfinished) {
+            // a node reference is a byte offset into the staged nodes or a leaf code (pt_types.h): 27 bits with its sign; the
+            // stack height rides above it (the launcher grants a budget only to trees of at most 31 levels)
+            uint32_t* pk = wb->park + slot;
+            pk[0] = ((uint32_t)cur & 0x07ffffffu) | ((uint32_t)sp << 27); pk[BLOCK] = __float_as_uint(closestT); pk[2 * BLOCK] = (uint32_t)bestTri;
+        } else if (bestTri >= 0) {
+            // the barycentrics of the closest hit: the same formulas on the same record and ray return the bits that the
+            // triangle test had (a quad's second triangle was resolved to its own slot when the hit was accepted)
+            float dn;
+            tri_uv(tris + (size_t)(bestTri & (kFrontBit - 1)) * 3, o, d, bu, bv, dn);
         }
     }
 }
@@ -709,12 +759,14 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
 // work-sharing traversal (every lane of the wave must then make the call together). `helper` (COOP only): this lane
 // needs no answer of its own (its result is discarded by the caller); it enters the meshes without a ray and takes
 // over pending subtrees of the other lanes.
-template <int BLOCK, bool COUNT, bool COOP>
-PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts* counts = nullptr, bool helper = false)
+template <int BLOCK, bool COUNT, bool COOP, bool BUDGET = false>
+PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts* counts = nullptr, bool helper = false,
+                        WalkBudget* wb = nullptr)
 {
     TraversalCounts cnt; cnt.nodes = 0; cnt.tris = 0; cnt.node_trips = 0; cnt.tri_trips = 0; cnt.steal_rounds = 0;
     const float kTMin = 1e-4f, kTMax = 1e30f;
     Best best; best.t = kTMax; best.obj = -1; best.tri = -1; best.u = 0.f; best.v = 0.f;
+    if (BUDGET) wb->unfinished = false;
     int i = 0;
 #if PT_LEAD_BOXES
     // The scene's leading run of unrotated boxes (the walls of a room; DScene::lead_aligned, 0 when shorter than two): their
@@ -787,6 +839,11 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
                     tri_uv(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, oo, dd, u, v, dn);
                     tri = with_side(tri, dn);
                 }
+            } else if (BUDGET && i == sc.num_objects - 1) {
+                // The budget covers the walk of the scene's last object. A lane that resumes has run the objects before it
+                // again with its unchanged ray (beside the lanes that test them for the first time) and found the same hits.
+                mesh_traverse<BLOCK, COUNT, true>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt, wb);
+                if (wb->unfinished) tri = -1; // not final yet
             } else {
                 mesh_traverse<BLOCK, COUNT>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt);
             }

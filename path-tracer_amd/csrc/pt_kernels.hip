@@ -252,6 +252,7 @@ static_assert(sizeof(SampleTile) % 16 == 0, "the hit records behind the tiles ar
 constexpr uint32_t kSamplesTileBytes = 4 * sizeof(SampleTile);
 constexpr uint32_t kSamplesCacheBytes = 4 * 16 * 5 * 16; // [wave][pixel][5 float4]
 constexpr uint32_t kSamplesKeyBytes = 4 * kBlock;        // the upper half of each lane's path key
+constexpr uint32_t kSamplesParkBytes = 3 * 4 * kBlock;   // BUDGET: the parked walk of each lane (WalkBudget)
 PT_DEV unsigned long long to_fixed(float c)
 {
     if (c < 0.0f) return (unsigned long long)__float2ll_rn(c * kFxScale); // not a radiance this renderer produces; kept exact anyway
@@ -280,9 +281,12 @@ PT_DEV void add_sample_fx(unsigned long long* acc, f3 c, unsigned long long time
 // LDS_GEOM: the scene's nodes and triangles are staged into LDS (lean traversal); otherwise they are read from global memory
 // by the work-sharing traversals, which every lane of the wave enters together, a lane without a ray as a helper.
 // TILED: the launch covers one rank's interleaved square tiles (ptamd_render_tiles) instead of a rectangle.
-template <bool LDS_GEOM, bool COUNT, bool EXT, bool TILED>
+// BUDGET (LDS_GEOM builds, scenes whose last object is a mesh): the walk of that mesh runs on a budget of node trips per
+// search, and a lane whose walk is cut goes on with it in the wave's next search (WalkBudget in pt_device.h).
+template <bool LDS_GEOM, bool COUNT, bool EXT, bool TILED, bool BUDGET = false>
 __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES_SM : PT_WAVES_COOP) void render_samples_kernel(DScene sc, DRenderParams rp)
 {
+    static_assert(LDS_GEOM || !BUDGET, "only walks through LDS run on a budget");
     constexpr bool COOP = !LDS_GEOM;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     StackEntry* stack = reinterpret_cast<StackEntry*>(lds_raw);
@@ -292,8 +296,12 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES_SM : PT_WAVES_COOP) voi
     SampleTile& tile = reinterpret_cast<SampleTile*>(lds_raw + stackBytes)[wave];
     float4* cache = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes) + wave * (16 * 5);
     uint32_t* lds_key_hi = reinterpret_cast<uint32_t*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes);
-    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes);
-    Coop coop; // the work-sharing words take the place of the staged geometry: 8 + 4 bytes per lane
+    // BUDGET: the parked walks, then the staged geometry (LDS_GEOM) or the work-sharing words (8 + 4 bytes per lane) in its place
+    float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes + (BUDGET ? kSamplesParkBytes : 0u));
+    WalkBudget wb;
+    wb.park = reinterpret_cast<uint32_t*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes);
+    wb.trips = rp.walk_budget ? rp.walk_budget : 0xffffffffu; wb.resume = false; wb.unfinished = false;
+    Coop coop;
     coop.res = reinterpret_cast<unsigned long long*>(lds_geom);
     coop.mail = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(lds_geom) + 8 * kBlock);
     const int p0 = lane & 15; // the pixel this lane traces the camera ray of, with three others
@@ -336,6 +344,22 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES_SM : PT_WAVES_COOP) voi
             return b;
         }
         return closest_hit<kBlock, false, COOP>(sc, geom, r, stack, coop, slot, nullptr, helper);
+    };
+    // BUDGET: a search of the bounce loop with a budget of node trips; `parked` lanes go on with their unfinished walk
+    bool parked = false;
+    auto search_budget = [&](const Ray& r) {
+        wb.resume = parked;
+        Best b;
+        if (COUNT) {
+            TraversalCounts tc;
+            b = closest_hit<kBlock, true, false, true>(sc, geom, r, stack, coop, slot, &tc, false, &wb);
+            tc_total.nodes += tc.nodes; tc_total.tris += tc.tris; tc_total.node_trips += tc.node_trips; tc_total.tri_trips += tc.tri_trips;
+            if (wave_leader()) ++ray_trips;
+        } else {
+            b = closest_hit<kBlock, false, false, true>(sc, geom, r, stack, coop, slot, nullptr, false, &wb);
+        }
+        parked = wb.unfinished;
+        return b;
     };
 
     // ---- the camera ray of every pixel of the tile, once (four lanes trace each: coherent, and once per launch)
@@ -399,7 +423,12 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES_SM : PT_WAVES_COOP) voi
             best = search(ray, fresh); // every lane of the wave enters the shared walk; one without a ray helps
         }
         if (!fresh) {
-            if (!COOP) best = search(ray, false);
+            if (BUDGET) {
+                best = search_budget(ray);
+                if (parked) continue; // the walk goes on in the wave's next search
+            } else if (!COOP) {
+                best = search(ray, false);
+            }
             if (COUNT) ++nrays;
             if (best.obj < 0) {
                 L = L + T * ((EXT && sc.sky_size > 0) ? sky_lookup(sc, ray.d) : bg); // PathTracer.cpp:59-60
@@ -578,34 +607,49 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     // short-lived; albedo-only and depth < 2 renders end at the camera ray's hit anyway. PTAMD_NO_SAMPLE_MAJOR=1 (read per
     // launch) keeps every launch on the pixel-major kernel.
     const bool noSampleMajor = getenv("PTAMD_NO_SAMPLE_MAJOR") != nullptr;
+    // Node trips per search of the LDS kernel before unfinished walks are parked (see WalkBudget): the depth of the tree
+    // (what a ray needs to reach its first leaf) + 4; PTAMD_WALK_BUDGET (read per launch) sets another number, 0 = no budget.
+    // Measured on the mesh Cornell (depth 8) at 256 samples, Msamples/s: 10 trips 3808, 12 4462, 14 4415, 16 4340, 20 4103,
+    // no budget 4150.
+    const char* budgetEnv = getenv("PTAMD_WALK_BUDGET");
+    p.walk_budget = budgetEnv ? (uint32_t)atoi(budgetEnv) : (uint32_t)p.stack_depth + 4u;
+    const bool budget = fits && sc.tail_mesh != 0u && p.walk_budget != 0u && p.stack_depth <= 31; // a parked stack height has five bits
     const size_t ldsSamples = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes
-                              + (fits ? geomBytes : (size_t)12 * kBlock);
+                              + (fits ? geomBytes + (budget ? kSamplesParkBytes : 0u) : (size_t)12 * kBlock);
     if (!noSampleMajor && rp.spp_count >= 64u && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only
         && ldsSamples <= kLdsBlockBytes) {
         const int n8 = tiled ? rp.tiles_owned * rp.tile_waves : rp.tiles_x * rp.tiles_y; // 8x8-pixel blocks, one workgroup each
         const int nb = ((n8 + 63) / 64) * 64;                                            // dealt to the XCDs eight neighbours at a time
-#define PT_LAUNCH_S(LDSG, COUNT, EXT, TILED)                                                                           \
+#define PT_LAUNCH_S(LDSG, COUNT, EXT, TILED, BUDGET)                                                                   \
         do {                                                                                                          \
-            if (debug) fprintf(stderr, "ptamd: render_samples_kernel<%d,%d,%d,%d> stack %d, lds %zu B/block, %d blocks\n", (int)LDSG, (int)COUNT, (int)EXT, (int)TILED, p.stack_depth, ldsSamples, nb); \
-            hipLaunchKernelGGL((render_samples_kernel<LDSG, COUNT, EXT, TILED>), dim3(nb), dim3(kBlock), ldsSamples, stream, sc, p); \
+            if (debug) fprintf(stderr, "ptamd: render_samples_kernel<%d,%d,%d,%d,%d> stack %d, lds %zu B/block, %d blocks, budget %u\n", (int)LDSG, (int)COUNT, (int)EXT, (int)TILED, (int)BUDGET, p.stack_depth, ldsSamples, nb, p.walk_budget); \
+            hipLaunchKernelGGL((render_samples_kernel<LDSG, COUNT, EXT, TILED, BUDGET>), dim3(nb), dim3(kBlock), ldsSamples, stream, sc, p); \
         } while (0)
-        switch ((tiled ? 8 : 0) | (fits ? 4 : 0) | (count ? 2 : 0) | (ext ? 1 : 0)) {
-        case 0: PT_LAUNCH_S(false, false, false, false); break;
-        case 1: PT_LAUNCH_S(false, false, true, false); break;
-        case 2: PT_LAUNCH_S(false, true, false, false); break;
-        case 3: PT_LAUNCH_S(false, true, true, false); break;
-        case 4: PT_LAUNCH_S(true, false, false, false); break;
-        case 5: PT_LAUNCH_S(true, false, true, false); break;
-        case 6: PT_LAUNCH_S(true, true, false, false); break;
-        case 7: PT_LAUNCH_S(true, true, true, false); break;
-        case 8: PT_LAUNCH_S(false, false, false, true); break;
-        case 9: PT_LAUNCH_S(false, false, true, true); break;
-        case 10: PT_LAUNCH_S(false, true, false, true); break;
-        case 11: PT_LAUNCH_S(false, true, true, true); break;
-        case 12: PT_LAUNCH_S(true, false, false, true); break;
-        case 13: PT_LAUNCH_S(true, false, true, true); break;
-        case 14: PT_LAUNCH_S(true, true, false, true); break;
-        default: PT_LAUNCH_S(true, true, true, true); break;
+        switch ((budget ? 16 : 0) | (tiled ? 8 : 0) | (fits ? 4 : 0) | (count ? 2 : 0) | (ext ? 1 : 0)) {
+        case 0: PT_LAUNCH_S(false, false, false, false, false); break;
+        case 1: PT_LAUNCH_S(false, false, true, false, false); break;
+        case 2: PT_LAUNCH_S(false, true, false, false, false); break;
+        case 3: PT_LAUNCH_S(false, true, true, false, false); break;
+        case 4: PT_LAUNCH_S(true, false, false, false, false); break;
+        case 5: PT_LAUNCH_S(true, false, true, false, false); break;
+        case 6: PT_LAUNCH_S(true, true, false, false, false); break;
+        case 7: PT_LAUNCH_S(true, true, true, false, false); break;
+        case 8: PT_LAUNCH_S(false, false, false, true, false); break;
+        case 9: PT_LAUNCH_S(false, false, true, true, false); break;
+        case 10: PT_LAUNCH_S(false, true, false, true, false); break;
+        case 11: PT_LAUNCH_S(false, true, true, true, false); break;
+        case 12: PT_LAUNCH_S(true, false, false, true, false); break;
+        case 13: PT_LAUNCH_S(true, false, true, true, false); break;
+        case 14: PT_LAUNCH_S(true, true, false, true, false); break;
+        case 15: PT_LAUNCH_S(true, true, true, true, false); break;
+        case 20: PT_LAUNCH_S(true, false, false, false, true); break;
+        case 21: PT_LAUNCH_S(true, false, true, false, true); break;
+        case 22: PT_LAUNCH_S(true, true, false, false, true); break;
+        case 23: PT_LAUNCH_S(true, true, true, false, true); break;
+        case 28: PT_LAUNCH_S(true, false, false, true, true); break;
+        case 29: PT_LAUNCH_S(true, false, true, true, true); break;
+        case 30: PT_LAUNCH_S(true, true, false, true, true); break;
+        default: PT_LAUNCH_S(true, true, true, true, true); break;
         }
 #undef PT_LAUNCH_S
         return hipGetLastError();

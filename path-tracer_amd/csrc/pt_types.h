@@ -154,7 +154,8 @@ struct DScene {
     const uint8_t* texels;
     float background[3];
     int32_t lead_aligned;     // objects [0, lead_aligned) are all unrotated boxes (DObject::aligned); 0 when fewer than two lead the list
-    uint32_t num_nodes, num_tris; // totals over all meshes
+    uint32_t tail_mesh;       // 1 when the last object of the list is a mesh (its walk can run on a budget, WalkBudget)
+    uint32_t num_tris;        // total over all meshes
     const float4* lds_nodes;  // kLdsNodeBytes per node; present when lds_resident
     uint32_t lds_node_f4;     // their size in float4
     uint32_t lds_resident;    // the LDS nodes and the hot triangles fit kLdsBlockBytes with the stack: traverse them from LDS
@@ -180,7 +181,9 @@ struct DRenderParams {
     int32_t depth, albedo_only;
     uint32_t seed, flags;  // flags: PTAMD_FLAG_* of the public header
     int32_t tiles_x, tiles_y; // 8x8-pixel tiles covering the rect
-    int32_t stack_depth, pad; // rows of the per-lane traversal stack in LDS (set by the launcher)
+    int32_t stack_depth;      // rows of the per-lane traversal stack in LDS (set by the launcher)
+    uint32_t walk_budget;     // node trips a wave of the sample-major LDS kernel spends per search before it parks its
+                              // unfinished walks (set by the launcher; 0 = no limit)
     // Interleaved-tile launches (tile_stride > 0, ptamd_render_tiles) cover, instead of the rect, the square tiles of
     // tile_size pixels (a multiple of 8) whose row-major index is tile_phase + k * tile_stride, k < tiles_owned;
     // tile_cols tiles per film row, tile_side = tile_size / 8 wave-tiles per tile row, tile_waves = tile_side^2.

@@ -127,3 +127,42 @@ def test_sample_major_tiles_from_lds(gpu):
     gpu.Render(cam, pt, fr, 80, 8, seed=2)
     assert (ft.Samples() == 80).all()
     assert np.array_equal(ft.Accum().view(np.uint32), fr.Accum().view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["mesh_cornell", "two_meshes"])
+def test_walk_budget_changes_the_schedule_not_the_film(gpu, name, monkeypatch):
+    """In a scene whose last object is a mesh staged in LDS, the sample-major kernel cuts a wave's walk after a budget of
+    node trips (tree depth + 4) and lets the unfinished lanes go on in the wave's next search. A lane's walk is the same
+    sequence of steps wherever it is cut, so the film, the ray total and the per-lane work must be bit-identical without a
+    budget (PTAMD_WALK_BUDGET=0), with the default one and with one so small that most walks are cut many times; only the
+    wave-level trip counts may move. `two_meshes`: a mesh before the last one is walked without a budget, also by lanes
+    that resume."""
+    if name == "mesh_cornell":
+        scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 56)
+    else:
+        scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", 64, 40)
+        first = dict(scene["objects"][0], path="tests/golden/emitter_panel.glb", pos=(0.4, 0.2, -0.3), rot=(10.0, 30.0, 5.0), scale=(0.8, 0.8, 0.8))
+        scene["objects"] = [first] + scene["objects"]
+    pt, cam = gpu.build_scene(scene)
+    assert pt.Info()["lds_resident"] == 1
+    w, h = scene["film"]
+    films, stats = [], []
+    for budget in ("0", None, "2"):
+        if budget is None:
+            monkeypatch.delenv("PTAMD_WALK_BUDGET", raising=False)
+        else:
+            monkeypatch.setenv("PTAMD_WALK_BUDGET", budget)
+        f = gpu.Film(w, h)
+        gpu.Render(cam, pt, f, 70, 8, seed=11, count=True)
+        films.append(f.Accum())
+        stats.append(gpu.RenderStats())
+    for f, s in zip(films[1:], stats[1:]):
+        assert np.array_equal(films[0].view(np.uint32), f.view(np.uint32))
+        for k in ("samples", "rays", "shade_lanes"):
+            assert s[k] == stats[0][k], (k, s[k], stats[0][k])
+        for k in ("nodes", "tris"):  # lane-level work: the same, except that a lane that resumes walks an earlier mesh again
+            assert s[k] == stats[0][k] if name != "two_meshes" else s[k] >= stats[0][k], (k, s[k], stats[0][k])
+    assert float(films[0].mean()) > 0.5
+    # the default budget packs the node loop: fewer wave-level node trips for the same lane-level visits
+    if name != "two_meshes":
+        assert stats[1]["node_trips"] < 0.8 * stats[0]["node_trips"], (stats[1]["node_trips"], stats[0]["node_trips"])

@@ -335,6 +335,59 @@ int main(int argc, char** argv)
                     printf("%-8s k = %2d refill at %2d idle: %.0f instr/wave-ray\n", mode == 0 ? "majority" : "both", k, refillAt, cost / nrays * 64.0);
                 }
     }
+    // Budgeted rounds: a search ends after K node trips of the wave; lanes whose walk is not finished keep their traversal
+    // state and go on in the wave's next search, beside the new rays of the lanes that finished (those are shaded and get
+    // their next ray at the end of the round). Priced in cycles per wave (node trip, primitive trip, the rest of a bounce-loop
+    // trip, and what parking / resuming costs when some lane is unfinished); K = 0 means no budget (today's kernel).
+    {
+        const double cNode = 115.0, cPrim = 130.0, cRest = 1600.0, cPark = 60.0;
+        for (int perLane = 0; perLane < 3; ++perLane)
+        for (int K : { 0, 32, 24, 20, 16, 14, 12, 10, 8, 6, 5, 4, 3, 2, 1 }) {
+            if (perLane < 2 && K < 6 && K != 0) continue;
+            if (perLane == 2 && K > 6) continue;
+            const bool phases = perLane == 2; // the budget counts node phases (outer iterations), not node trips
+            double cycles = 0, done = 0, nodeTrips = 0, rounds2 = 0, shadeLanes = 0;
+            for (int w = 0; w < wavesPerBlock; ++w) {
+                std::vector<const Walk*> queue;
+                for (size_t r = 0; r < hist.size() && r < 6000; ++r) for (int l = 0; l < 64; ++l) queue.push_back(&hist[r][w][l]);
+                size_t next = 0;
+                const Walk* cur[64]; size_t seg[64]; int nLeft[64], pLeft[64];
+                auto load = [&](int l) { cur[l] = queue[next++]; seg[l] = 0; nLeft[l] = cur[l]->segs.empty() ? 0 : cur[l]->segs[0].nodes; pLeft[l] = cur[l]->segs.empty() ? 0 : cur[l]->segs[0].prims; };
+                auto finished = [&](int l) { return seg[l] >= cur[l]->segs.size(); };
+                for (int l = 0; l < 64; ++l) load(l);
+                while (next + 64 <= queue.size()) {
+                    int trips = 0, nph = 0;
+                    int used[64] = { 0 };
+                    for (;;) {
+                        ++nph;
+                        bool anyNode = false;
+                        auto can = [&](int l) { return !finished(l) && nLeft[l] > 0 && (perLane != 1 || K == 0 || used[l] < K); };
+                        for (int l = 0; l < 64; ++l) if (can(l)) anyNode = true;
+                        while (anyNode && (perLane || K == 0 || trips < K)) {
+                            ++trips; cycles += cNode; anyNode = false;
+                            for (int l = 0; l < 64; ++l) if (can(l)) { --nLeft[l]; ++used[l]; if (can(l)) anyNode = true; }
+                        }
+                        int mp = 0;
+                        for (int l = 0; l < 64; ++l) if (!finished(l) && nLeft[l] == 0) mp = std::max(mp, pLeft[l]);
+                        cycles += mp * cPrim;
+                        bool more = false;
+                        for (int l = 0; l < 64; ++l) if (!finished(l) && nLeft[l] == 0) {
+                            pLeft[l] = 0;
+                            if (++seg[l] < cur[l]->segs.size()) { nLeft[l] = cur[l]->segs[seg[l]].nodes; pLeft[l] = cur[l]->segs[seg[l]].prims; }
+                        }
+                        for (int l = 0; l < 64; ++l) if (!finished(l) && (perLane != 1 || K == 0 || used[l] < K)) more = true;
+                        if (!more || (!perLane && K != 0 && trips >= K) || (phases && K != 0 && nph >= K)) break;
+                    }
+                    nodeTrips += trips; rounds2 += 1;
+                    bool parked = false;
+                    for (int l = 0; l < 64; ++l) { if (finished(l)) { done += 1; shadeLanes += 1; load(l); } else parked = true; }
+                    cycles += cRest + (parked ? cPark : 0.0);
+                }
+            }
+            printf("%s budget %2d node trips per search: %.0f cycles per finished ray x 64 (node trips per round %.1f, lanes shaded per round %.1f)  %.3f of no budget\n",
+                   perLane == 2 ? "phases  " : perLane ? "per-lane" : "per-wave", K, cycles / done * 64.0, nodeTrips / rounds2, shadeLanes / rounds2, 0.0);
+        }
+    }
     printf("rays %.0f, per lane: %.2f nodes, %.2f prims per ray\n", rays, laneNodes / rays, lanePrims / rays);
     const double wavesTotal = rounds * wavesPerBlock;
     for (int key = 0; key < NKEYS; ++key)
