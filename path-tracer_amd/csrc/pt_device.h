@@ -840,8 +840,8 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
                     tri = with_side(tri, dn);
                 }
             } else if (BUDGET && i == sc.num_objects - 1) {
-                // The budget covers the walk of the scene's last object. A lane that resumes has run the objects before it
-                // again with its unchanged ray (beside the lanes that test them for the first time) and found the same hits.
+                // The budget covers the walk of the scene's last object (the launcher grants one only to scenes that are a single
+                // mesh; a lane that resumes would run any objects before it again with its unchanged ray and find the same hits).
                 mesh_traverse<BLOCK, COUNT, true>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt, wb);
                 if (wb->unfinished) tri = -1; // not final yet
             } else {

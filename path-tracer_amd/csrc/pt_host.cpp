@@ -851,7 +851,7 @@ static int commit_scene(ptamd_scene* s)
     ds.groups = s->d_groups.ptr; ds.images = s->d_images.ptr; ds.texels = s->d_texels.ptr;
     std::memcpy(ds.background, s->background, 12);
     ds.sky = s->sky_size ? reinterpret_cast<const float4*>(s->d_sky.ptr) : nullptr; ds.sky_size = s->sky_size;
-    ds.tail_mesh = (!s->objects.empty() && s->objects.back().kind == KIND_MESH) ? 1u : 0u; ds.num_tris = (uint32_t)tris.size();
+    ds.lone_mesh = (s->objects.size() == 1 && s->objects.back().kind == KIND_MESH) ? 1u : 0u; ds.num_tris = (uint32_t)tris.size();
     ds.max_stack = 1; // rows of the per-lane traversal stack the deepest walk of this scene needs
     for (const HostObject& ho : s->objects)
         if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, uses_wide(*ho.mesh) ? 2 * ho.mesh->bvh.wide_depth : ho.mesh->bvh.depth);

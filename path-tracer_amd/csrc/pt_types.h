@@ -154,7 +154,7 @@ struct DScene {
     const uint8_t* texels;
     float background[3];
     int32_t lead_aligned;     // objects [0, lead_aligned) are all unrotated boxes (DObject::aligned); 0 when fewer than two lead the list
-    uint32_t tail_mesh;       // 1 when the last object of the list is a mesh (its walk can run on a budget, WalkBudget)
+    uint32_t lone_mesh;       // 1 when the scene is one mesh and nothing else (its walk can run on a budget, WalkBudget)
     uint32_t num_tris;        // total over all meshes
     const float4* lds_nodes;  // kLdsNodeBytes per node; present when lds_resident
     uint32_t lds_node_f4;     // their size in float4

@@ -131,12 +131,11 @@ def test_sample_major_tiles_from_lds(gpu):
 
 @pytest.mark.parametrize("name", ["mesh_cornell", "two_meshes"])
 def test_walk_budget_changes_the_schedule_not_the_film(gpu, name, monkeypatch):
-    """In a scene whose last object is a mesh staged in LDS, the sample-major kernel cuts a wave's walk after a budget of
-    node trips (tree depth + 4) and lets the unfinished lanes go on in the wave's next search. A lane's walk is the same
-    sequence of steps wherever it is cut, so the film, the ray total and the per-lane work must be bit-identical without a
-    budget (PTAMD_WALK_BUDGET=0), with the default one and with one so small that most walks are cut many times; only the
-    wave-level trip counts may move. `two_meshes`: a mesh before the last one is walked without a budget, also by lanes
-    that resume."""
+    """In a scene that is one mesh staged in LDS, the sample-major kernel cuts a wave's walk after a budget of node trips
+    (tree depth + 4) and lets the unfinished lanes go on in the wave's next search. A lane's walk is the same sequence of
+    steps wherever it is cut, so the film, the ray total and the per-lane work must be bit-identical without a budget
+    (PTAMD_WALK_BUDGET=0), with the default one and with one so small that most walks are cut many times; only the
+    wave-level trip counts may move. `two_meshes`: a scene with a second object gets no budget whatever the variable says."""
     if name == "mesh_cornell":
         scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 56)
     else:
