@@ -615,9 +615,11 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     // no budget 4150.
     const char* budgetEnv = getenv("PTAMD_WALK_BUDGET");
     p.walk_budget = budgetEnv ? (uint32_t)atoi(budgetEnv) : (uint32_t)p.stack_depth + 4u;
-    const bool budget = fits && sc.lone_mesh != 0u && p.walk_budget != 0u && p.stack_depth <= 31; // a parked stack height has five bits
-    const size_t ldsSamples = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes
-                              + (fits ? geomBytes + (budget ? kSamplesParkBytes : 0u) : (size_t)12 * kBlock);
+    const size_t ldsPlain = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes
+                            + (fits ? geomBytes : (size_t)12 * kBlock);
+    const bool budget = fits && sc.lone_mesh != 0u && p.walk_budget != 0u && p.stack_depth <= 31 // a parked stack height has five bits
+                        && ldsPlain + kSamplesParkBytes <= kLdsBlockBytes;                       // the parked walks must not cost the scene this kernel
+    const size_t ldsSamples = ldsPlain + (budget ? kSamplesParkBytes : 0u);
     if (!noSampleMajor && rp.spp_count >= 64u && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only
         && ldsSamples <= kLdsBlockBytes) {
         const int n8 = tiled ? rp.tiles_owned * rp.tile_waves : rp.tiles_x * rp.tiles_y; // 8x8-pixel blocks, one workgroup each
