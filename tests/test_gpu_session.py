@@ -123,6 +123,17 @@ def test_leading_run_of_unrotated_boxes_changes_no_image_and_follows_edits(gpu):
     hits = pt.ClosestHits(np.load("tests/golden/box_cornell.npz")["rays"])
     hits0 = pt0.ClosestHits(np.load("tests/golden/box_cornell.npz")["rays"])
     assert np.array_equal(hits.view(np.uint32), hits0.view(np.uint32))
+    # the spheres that follow the walls share d.d and its reciprocal (Sphere.cpp:36,46-48): same film as behind a leading sphere,
+    # where neither run exists
+    room = presets.sphere_cornell(80, 60)
+    rs, cs = gpu.build_scene(room)
+    r0, c0 = gpu.build_scene(dict(room, objects=behind["objects"][:1] + room["objects"]))
+    assert rs.Info()["leading_boxes"] == 7 and r0.Info()["leading_boxes"] == 0
+    for spp in (3, 64):
+        a, b = gpu.Film(80, 60), gpu.Film(80, 60)
+        gpu.Render(cs, rs, a, spp, 5, seed=9)
+        gpu.Render(c0, r0, b, spp, 5, seed=9)
+        assert np.array_equal(a.Accum().view(np.uint32), b.Accum().view(np.uint32))
     # an edit that rotates the second wall ends the run after the first box (one box is no run); undoing it restores it
     first = pt.GetRayObjects()[1]
     first.SetRotation((0.0, 0.0, 3.0)); pt.Commit()
