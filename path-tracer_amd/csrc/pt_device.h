@@ -274,14 +274,18 @@ struct TraversalCounts { uint32_t nodes, tris, node_trips, tri_trips, steal_roun
 PT_DEV bool wave_leader() { return (int)__lane_id() == __ffsll((unsigned long long)__ballot(1)) - 1; }
 typedef uint32_t StackEntry;
 
-// A search with a budget (sample-major kernel on LDS-resident scenes). A wave pays for the longest of its 64 walks: 26 node
-// trips for 9 visits per lane on the mesh Cornell. With a budget the wave leaves the walk after `trips` node trips; a lane
-// whose walk is not finished parks its traversal state (six words in LDS; its stack column stays where it is) and goes on
-// in the wave's next search, beside the new rays of the lanes that finished, which are shaded in between. The walk of a
-// lane is the same sequence of steps either way, so its closest hit (and which of two equal hits it keeps) does not change.
+#ifndef PT_CUT_STEPS
+#define PT_CUT_STEPS 2
+#endif
+// A search that cuts its tail (sample-major kernel, scenes that are one LDS-resident mesh). A wave pays for the longest of
+// its 64 walks: 26 node trips for 9 visits per lane on the mesh Cornell. With a cut the wave leaves the walk when the lanes
+// still walking are down to `cut64` 64ths of those that entered it; a lane whose walk is not finished parks its traversal
+// state (three words in LDS; its stack column stays where it is) and goes on in the wave's next search, beside the new rays
+// of the lanes that finished, which are shaded in between. The walk of a lane is the same sequence of steps either way, so
+// its closest hit (and which of two equal hits it keeps) does not change.
 struct WalkBudget {
     uint32_t* park;   // LDS, [3][BLOCK]: node reference with the stack height above it, closest distance, triangle
-    uint32_t trips;   // node trips the wave may spend in one search (wave-uniform)
+    uint32_t cut64;   // 1..63 (wave-uniform)
     bool resume;      // in: the lane goes on with its parked walk
     bool unfinished;  // out: the lane's walk is parked again
 };
@@ -357,20 +361,25 @@ PT_DEV void mesh_traverse(const DScene& sc, const Geom& geom, const DMesh& me, f
             if (cur < 0) leaf_pass();
         }
     } else {
-        // The same two phases with wave-uniform loop conditions, so that the trips are counted once per wave (a counter in
-        // a loop that lanes leave one by one would be a counter per lane).
-        uint32_t left = wb->trips;
+        // The same two phases with wave-uniform loop conditions (the number of lanes still walking is a property of the wave).
+        // At least one walk has ended when the cut comes, and a wave of fewer than 64 / cut64 lanes is never cut, so every
+        // search makes progress.
+        const uint32_t started = (uint32_t)__popcll(__ballot(cur != kDone));
+        const uint32_t floorLanes = (started * wb->cut64) >> 6;
+        bool cut = false;
         for (;;) {
-            bool go = (uint32_t)cur < (uint32_t)kDone && left != 0u;
-            if (__any(go)) {
-                do {
-                    --left;
-                    if (go) node_step();
-                    go = (uint32_t)cur < (uint32_t)kDone && left != 0u;
-                } while (__any(go));
+            bool go = (uint32_t)cur < (uint32_t)kDone;
+            while (__any(go)) { // PT_CUT_STEPS node steps per pass: the loop's own tests and branches cost a twelfth of a step each
+                if ((uint32_t)__popcll(__ballot(cur != kDone)) <= floorLanes) { cut = true; break; }
+                if (go) node_step();
+#pragma unroll
+                for (int extra = 1; extra < PT_CUT_STEPS; ++extra)
+                    if ((uint32_t)cur < (uint32_t)kDone) node_step();
+                go = (uint32_t)cur < (uint32_t)kDone;
             }
             if (cur < 0) leaf_pass();
-            if (!__any(cur != kDone && left != 0u)) break;
+            const uint32_t walking = (uint32_t)__popcll(__ballot(cur != kDone));
+            if (cut || walking == 0u || walking <= floorLanes) break;
         }
         wb->unfinished = cur != kDone;
         if (wb->unfinished) {

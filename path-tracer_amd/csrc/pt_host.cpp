@@ -104,6 +104,10 @@ struct ptamd_scene {
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
     DevBuf<float> d_sky; int sky_size = 0;
     unsigned long long* d_counters = nullptr; // this scene's PTAMD_FLAG_COUNT tallies (allocated by its first counting render)
+    // Walk cut of the sample-major LDS kernel (scenes that are one mesh): -1 = not measured yet for (film size, depth); else
+    // the 64ths of a wave's walking lanes at which a walk is cut, 0 = never. Measured at the first eligible launch after a
+    // commit (tune_walk_cut).
+    int walk_cut = -1, walk_cut_w = 0, walk_cut_h = 0, walk_cut_depth = 0;
     DScene dscene;
     void release() // what commit rebuilds; the sky map is uploaded by its own call and outlives commits
     {
@@ -623,6 +627,7 @@ int ptamd_scene_commit(ptamd_scene* s)
 }
 static int commit_scene(ptamd_scene* s)
 {
+    s->walk_cut = -1; // an edit changes which walks are long: measured again at the next eligible launch
     const auto t_begin = std::chrono::steady_clock::now();
     auto seconds_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     if (!s->structure_dirty && s->h_objects.size() == s->objects.size()) {
@@ -874,6 +879,7 @@ int ptamd_scene_get_info(const ptamd_scene* s, ptamd_scene_info* out)
     out->triangles = s->dscene.num_tris; out->nodes = (uint32_t)s->d_nodes.count; out->wide_nodes = (uint32_t)s->d_wide.count;
     out->lds_resident = s->dscene.lds_resident;
     out->leading_boxes = (uint32_t)s->dscene.lead_aligned;
+    out->walk_cut = s->walk_cut < 0 ? 0xffffffffu : (uint32_t)s->walk_cut;
     out->geometry_uploads = s->geometry_uploads; out->row_updates = s->row_updates;
     out->last_commit_seconds = s->last_commit_seconds; out->last_bvh_seconds = s->last_bvh_seconds;
     out->d_nodes = s->d_wide.count ? (const void*)s->d_wide.ptr : (const void*)s->d_nodes.ptr; out->d_tris = s->d_tris.ptr; out->d_shade = s->d_shade.ptr;
@@ -1035,6 +1041,76 @@ int ptamd_film_device_ptrs(ptamd_film* f, void** a, void** s)
 }
 
 // ------------------------------------------------------------------------------- render
+// The walk cut (WalkBudget in pt_device.h) pays when a few long walks hold a wave (the mesh Cornell: +9 %) and costs when
+// all walks are about as long or the kernel runs at low occupancy (a camera inside a 192-triangle blob: -18 %); which of
+// the two a scene is shows in no count that the host could take at commit, so it is measured: the first launch that could
+// use the cut renders two bands of the frame at 64 samples, four times with and four times without it, into a scratch
+// film, and keeps the cut if its best time (of the last three) is 2 % under the other's. The bands together hold four times
+// the workgroups that the GPU keeps resident (a launch of fewer measures one workgroup's life, not the rate): 171 rows of
+// a 1080p frame, about 50 ms in all, once per commit and (film size, depth). The film does not depend on the choice.
+// PTAMD_WALK_BUDGET=<0..63> sets it without measuring.
+constexpr uint32_t kWalkCut = 24; // of 64: cut when the lanes still walking are down to 3/8 of those that entered the walk
+static int tune_walk_cut(ptamd_scene* s, const DRenderParams& user)
+{
+    const int W = user.cam.width, H = user.cam.height;
+    s->walk_cut_w = W; s->walk_cut_h = H; s->walk_cut_depth = user.depth;
+    s->walk_cut = 0;
+    const long long kProbeBlocks = 4 * 1280; // 8x8-pixel workgroups: four times 256 CUs x 5 resident workgroups
+    const int blocksPerStrip = (W + 7) / 8;
+    int rows = (int)((kProbeBlocks + blocksPerStrip - 1) / blocksPerStrip) * 8; // both bands together
+    rows = ((rows + 15) / 16) * 16 / 2;                                         // one band, a multiple of 8
+    if (3 * rows > H) return PTAMD_OK; // a film of fewer workgroups than that: not worth the launches
+    float* accum = nullptr; uint32_t* samples = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() { if (accum) (void)hipFree(accum); if (samples) (void)hipFree(samples); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
+    auto bail = [&](hipError_t e) { cleanup(); return fail(PTAMD_ERR_DEVICE, hipGetErrorString(e)); };
+    hipError_t e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&accum), (size_t)W * rows * 12)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&samples), (size_t)W * rows * 4)) != hipSuccess) return bail(e);
+    if ((e = hipMemsetAsync(accum, 0, (size_t)W * rows * 12, g_stream)) != hipSuccess) return bail(e);
+    if ((e = hipMemsetAsync(samples, 0, (size_t)W * rows * 4, g_stream)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) return bail(e);
+    float best[2] = { 3.0e38f, 3.0e38f };
+    for (int rep = 0; rep < 4; ++rep) // the first pass warms the caches and is not timed
+        for (int v = 0; v < 2; ++v) {
+            if ((e = hipEventRecord(e0, g_stream)) != hipSuccess) return bail(e);
+            for (int band = 1; band <= 2; ++band) {
+                DRenderParams rp = user;
+                rp.counters = nullptr; rp.flags &= ~(uint32_t)PTAMD_FLAG_COUNT;
+                rp.x0 = 0; rp.x1 = W; rp.y0 = band * H / 3 - rows / 2; rp.y1 = rp.y0 + rows;
+                // the band's first row is row 0 of the scratch film (the kernel addresses pixels as y * W + x)
+                rp.accum = accum - (size_t)rp.y0 * W * 3; rp.samples = samples - (size_t)rp.y0 * W;
+                rp.spp_begin = 0; rp.spp_count = 64;
+                rp.tiles_x = (W + 7) / 8; rp.tiles_y = rows / 8;
+                rp.tile_stride = 0;
+                rp.walk_budget = v ? kWalkCut : 0u;
+                if ((e = launch_render(s->dscene, rp, g_stream)) != hipSuccess) return bail(e);
+            }
+            if ((e = hipEventRecord(e1, g_stream)) != hipSuccess || (e = hipEventSynchronize(e1)) != hipSuccess) return bail(e);
+            float ms = 0.0f;
+            if ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) return bail(e);
+            if (rep > 0) best[v] = std::min(best[v], ms);
+        }
+    cleanup();
+    s->walk_cut = best[1] < 0.98f * best[0] ? (int)kWalkCut : 0;
+    if (std::getenv("PTAMD_DEBUG")) std::fprintf(stderr, "ptamd: walk cut measured: %.3f ms without, %.3f ms with -> %d/64\n", best[0], best[1], s->walk_cut);
+    return PTAMD_OK;
+}
+// The cut for this launch (DRenderParams::walk_budget). may_measure: the caller may allocate (the scratch film).
+static int walk_cut_for(ptamd_scene* s, const DRenderParams& rp, bool may_measure, uint32_t* out)
+{
+    *out = 0u;
+    if (!s->dscene.lds_resident || !s->dscene.lone_mesh) return PTAMD_OK;
+    if (rp.spp_count < 64u || rp.depth < 2 || rp.albedo_only) return PTAMD_OK; // launches that the sample-major kernel does not take
+    if (const char* env = std::getenv("PTAMD_WALK_BUDGET")) { *out = (uint32_t)std::min(63, std::max(0, std::atoi(env))); return PTAMD_OK; }
+    if (s->walk_cut < 0 || s->walk_cut_w != rp.cam.width || s->walk_cut_h != rp.cam.height || s->walk_cut_depth != rp.depth) {
+        if (!may_measure) return PTAMD_OK;
+        if (int rc = tune_walk_cut(s, rp)) return rc;
+    }
+    *out = (uint32_t)s->walk_cut;
+    return PTAMD_OK;
+}
+
 // counters: where a PTAMD_FLAG_COUNT launch tallies (kNumCounters x u64 of device memory, cleared here first); null = the
 // scene's own buffer
 static int render_impl(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
@@ -1077,6 +1153,7 @@ static int render_impl(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, u
         // TraceRay returns 0 at once (PathTracer.cpp:35-36): every sample adds black
         rp.depth = 0;
     }
+    if (int rc = walk_cut_for(s, rp, counters != g_static_counters, &rp.walk_budget)) return rc; // (the entry point that allocates nothing brings those counters)
     PT_HIP(launch_render(s->dscene, rp, g_stream));
     return PTAMD_OK;
 }

@@ -281,8 +281,8 @@ PT_DEV void add_sample_fx(unsigned long long* acc, f3 c, unsigned long long time
 // LDS_GEOM: the scene's nodes and triangles are staged into LDS (lean traversal); otherwise they are read from global memory
 // by the work-sharing traversals, which every lane of the wave enters together, a lane without a ray as a helper.
 // TILED: the launch covers one rank's interleaved square tiles (ptamd_render_tiles) instead of a rectangle.
-// BUDGET (LDS_GEOM builds, scenes that are one mesh and nothing else): the walk runs on a budget of node trips per search,
-// and a lane whose walk is cut goes on with it in the wave's next search (WalkBudget in pt_device.h). With other objects in
+// BUDGET (LDS_GEOM builds, scenes that are one mesh and nothing else): a wave cuts the tail of its walk, and a lane whose
+// walk is cut goes on with it in the wave's next search (WalkBudget in pt_device.h). With other objects in
 // the scene every extra search repeats their tests too, and the budget loses: a room of seven boxes and two spheres around
 // the same mesh renders at 2809 Msamples/s with it against 3514 without.
 template <bool LDS_GEOM, bool COUNT, bool EXT, bool TILED, bool BUDGET = false>
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES_SM : PT_WAVES_COOP) voi
     float4* lds_geom = reinterpret_cast<float4*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes + (BUDGET ? kSamplesParkBytes : 0u));
     WalkBudget wb;
     wb.park = reinterpret_cast<uint32_t*>(lds_raw + stackBytes + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes);
-    wb.trips = rp.walk_budget ? rp.walk_budget : 0xffffffffu; wb.resume = false; wb.unfinished = false;
+    wb.cut64 = rp.walk_budget; wb.resume = false; wb.unfinished = false;
     Coop coop;
     coop.res = reinterpret_cast<unsigned long long*>(lds_geom);
     coop.mail = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(lds_geom) + 8 * kBlock);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES_SM : PT_WAVES_COOP) voi
         }
         return closest_hit<kBlock, false, COOP>(sc, geom, r, stack, coop, slot, nullptr, helper);
     };
-    // BUDGET: a search of the bounce loop with a budget of node trips; `parked` lanes go on with their unfinished walk
+    // BUDGET: a search of the bounce loop that may be cut; `parked` lanes go on with their unfinished walk
     bool parked = false;
     auto search_budget = [&](const Ray& r) {
         wb.resume = parked;
@@ -609,12 +609,10 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     // short-lived; albedo-only and depth < 2 renders end at the camera ray's hit anyway. PTAMD_NO_SAMPLE_MAJOR=1 (read per
     // launch) keeps every launch on the pixel-major kernel.
     const bool noSampleMajor = getenv("PTAMD_NO_SAMPLE_MAJOR") != nullptr;
-    // Node trips per search of the LDS kernel before unfinished walks are parked (see WalkBudget): the depth of the tree
-    // (what a ray needs to reach its first leaf) + 4; PTAMD_WALK_BUDGET (read per launch) sets another number, 0 = no budget.
-    // Measured on the mesh Cornell (depth 8) at 256 samples, Msamples/s: 10 trips 3808, 12 4462, 14 4415, 16 4340, 20 4103,
-    // no budget 4150.
-    const char* budgetEnv = getenv("PTAMD_WALK_BUDGET");
-    p.walk_budget = budgetEnv ? (uint32_t)atoi(budgetEnv) : (uint32_t)p.stack_depth + 4u;
+    // rp.walk_budget (set by the host, 0 = none): the 64ths of a wave's walking lanes at which the LDS kernel cuts a walk and
+    // parks what is left of it (see WalkBudget). Measured on the mesh Cornell at 256 samples, Msamples/s: never 4150; 16: 4435;
+    // 20: 4484; 24: 4517; 32: 4270.
+    if (p.walk_budget > 63u) p.walk_budget = 63u;
     const size_t ldsPlain = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes
                             + (fits ? geomBytes : (size_t)12 * kBlock);
     const bool budget = fits && sc.lone_mesh != 0u && p.walk_budget != 0u && p.stack_depth <= 31 // a parked stack height has five bits

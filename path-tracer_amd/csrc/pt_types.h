@@ -182,8 +182,8 @@ struct DRenderParams {
     uint32_t seed, flags;  // flags: PTAMD_FLAG_* of the public header
     int32_t tiles_x, tiles_y; // 8x8-pixel tiles covering the rect
     int32_t stack_depth;      // rows of the per-lane traversal stack in LDS (set by the launcher)
-    uint32_t walk_budget;     // node trips a wave of the sample-major LDS kernel spends per search before it parks its
-                              // unfinished walks (set by the launcher; 0 = no limit)
+    uint32_t walk_budget;     // sample-major LDS kernel, scenes that are one mesh: the 64ths of a wave's walking lanes at which
+                              // it cuts a walk and parks what is left (WalkBudget; set by the host, 0 = never)
     // Interleaved-tile launches (tile_stride > 0, ptamd_render_tiles) cover, instead of the rect, the square tiles of
     // tile_size pixels (a multiple of 8) whose row-major index is tile_phase + k * tile_stride, k < tiles_owned;
     // tile_cols tiles per film row, tile_side = tile_size / 8 wave-tiles per tile row, tile_waves = tile_side^2.

@@ -67,7 +67,7 @@ class CSceneInfo(C.Structure):
                 ("wide_nodes", C.c_uint32), ("lds_resident", C.c_uint32), ("geometry_uploads", C.c_uint64),
                 ("row_updates", C.c_uint64), ("last_commit_seconds", C.c_double), ("last_bvh_seconds", C.c_double),
                 ("d_nodes", C.c_void_p), ("d_tris", C.c_void_p), ("d_shade", C.c_void_p),
-                ("leading_boxes", C.c_uint32), ("reserved", C.c_uint32)]
+                ("leading_boxes", C.c_uint32), ("walk_cut", C.c_uint32)]
 
 
 FLAG_COUNT = 1

@@ -130,12 +130,12 @@ def test_sample_major_tiles_from_lds(gpu):
 
 
 @pytest.mark.parametrize("name", ["mesh_cornell", "two_meshes"])
-def test_walk_budget_changes_the_schedule_not_the_film(gpu, name, monkeypatch):
-    """In a scene that is one mesh staged in LDS, the sample-major kernel cuts a wave's walk after a budget of node trips
-    (tree depth + 4) and lets the unfinished lanes go on in the wave's next search. A lane's walk is the same sequence of
-    steps wherever it is cut, so the film, the ray total and the per-lane work must be bit-identical without a budget
-    (PTAMD_WALK_BUDGET=0), with the default one and with one so small that most walks are cut many times; only the
-    wave-level trip counts may move. `two_meshes`: a scene with a second object gets no budget whatever the variable says."""
+def test_walk_cut_changes_the_schedule_not_the_film(gpu, name, monkeypatch):
+    """In a scene that is one mesh staged in LDS, the sample-major kernel can cut a wave's walk when few of its lanes are
+    still walking and let the unfinished lanes go on in the wave's next search. A lane's walk is the same sequence of steps
+    wherever it is cut, so the film, the ray total and the per-lane work must be bit-identical without the cut
+    (PTAMD_WALK_BUDGET=0), with the usual one (24 of 64 lanes) and with one so eager that most walks are cut many times; only
+    the wave-level trip counts may move. `two_meshes`: a scene with a second object is never cut whatever the variable says."""
     if name == "mesh_cornell":
         scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 56)
     else:
@@ -146,22 +146,52 @@ def test_walk_budget_changes_the_schedule_not_the_film(gpu, name, monkeypatch):
     assert pt.Info()["lds_resident"] == 1
     w, h = scene["film"]
     films, stats = [], []
-    for budget in ("0", None, "2"):
-        if budget is None:
-            monkeypatch.delenv("PTAMD_WALK_BUDGET", raising=False)
-        else:
-            monkeypatch.setenv("PTAMD_WALK_BUDGET", budget)
+    for cut in ("0", "24", "56"):
+        monkeypatch.setenv("PTAMD_WALK_BUDGET", cut)
         f = gpu.Film(w, h)
         gpu.Render(cam, pt, f, 70, 8, seed=11, count=True)
         films.append(f.Accum())
         stats.append(gpu.RenderStats())
     for f, s in zip(films[1:], stats[1:]):
         assert np.array_equal(films[0].view(np.uint32), f.view(np.uint32))
-        for k in ("samples", "rays", "shade_lanes"):
+        for k in ("samples", "rays", "nodes", "tris", "shade_lanes"):
             assert s[k] == stats[0][k], (k, s[k], stats[0][k])
-        for k in ("nodes", "tris"):  # lane-level work: the same, except that a lane that resumes walks an earlier mesh again
-            assert s[k] == stats[0][k] if name != "two_meshes" else s[k] >= stats[0][k], (k, s[k], stats[0][k])
     assert float(films[0].mean()) > 0.5
-    # the default budget packs the node loop: fewer wave-level node trips for the same lane-level visits
-    if name != "two_meshes":
+    if name == "mesh_cornell":  # the cut packs the node loop: fewer wave-level node trips for the same lane-level visits
         assert stats[1]["node_trips"] < 0.8 * stats[0]["node_trips"], (stats[1]["node_trips"], stats[0]["node_trips"])
+        assert stats[2]["ray_trips"] > stats[1]["ray_trips"] > stats[0]["ray_trips"]
+    else:
+        assert stats[1]["node_trips"] == stats[0]["node_trips"]
+
+
+def test_walk_cut_is_measured_once_per_commit_and_leaves_the_film_alone(gpu, monkeypatch):
+    """Without the variable the first launch of 64 samples and more on a scene that is one LDS-resident mesh measures whether
+    the cut pays (two bands of the frame, with and without) and keeps the answer until the next commit; launches that
+    cannot use it, the entry point that allocates nothing and small films measure nothing."""
+    monkeypatch.delenv("PTAMD_WALK_BUDGET", raising=False)
+    scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", 1280, 720)
+    pt, cam = gpu.build_scene(scene)
+    unknown = 0xffffffff
+    assert pt.Info()["walk_cut"] == unknown
+    few = gpu.Film(1280, 720)
+    gpu.Render(cam, pt, few, 8, 8, seed=3)          # under 64 samples: the pixel-major kernel, nothing to measure
+    assert pt.Info()["walk_cut"] == unknown
+    a = gpu.Film(1280, 720)
+    gpu.Render(cam, pt, a, 64, 8, seed=3)
+    chosen = pt.Info()["walk_cut"]
+    assert chosen in (0, 24)
+    print("walk cut chosen for the mesh Cornell at 1280x720:", chosen)
+    monkeypatch.setenv("PTAMD_WALK_BUDGET", "24" if chosen == 0 else "0")
+    b = gpu.Film(1280, 720)
+    gpu.Render(cam, pt, b, 64, 8, seed=3)           # the other choice: same film
+    assert np.array_equal(a.Accum().view(np.uint32), b.Accum().view(np.uint32))
+    assert pt.Info()["walk_cut"] == chosen          # the variable overrides, it does not overwrite
+    monkeypatch.delenv("PTAMD_WALK_BUDGET")
+    mesh = pt.GetRayObjects()[0]
+    mesh.SetRotation((0.0, 1.0, 0.0)); pt.Commit()  # an edit: measured again at the next eligible launch
+    assert pt.Info()["walk_cut"] == unknown
+    gpu.Render(cam, pt, gpu.Film(1280, 720), 64, 8, seed=3)
+    assert pt.Info()["walk_cut"] in (0, 24)
+    small, cam_s = gpu.build_scene(presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 56))
+    gpu.Render(cam_s, small, gpu.Film(96, 56), 64, 8, seed=3)
+    assert small.Info()["walk_cut"] == 0            # a small film: not worth the launches
