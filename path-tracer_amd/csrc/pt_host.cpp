@@ -1079,7 +1079,8 @@ static int tune_walk_cut(ptamd_scene* s, const DRenderParams& user)
                 rp.counters = nullptr; rp.flags &= ~(uint32_t)PTAMD_FLAG_COUNT;
                 rp.x0 = 0; rp.x1 = W; rp.y0 = band * H / 3 - rows / 2; rp.y1 = rp.y0 + rows;
                 // the band's first row is row 0 of the scratch film (the kernel addresses pixels as y * W + x)
-                rp.accum = accum - (size_t)rp.y0 * W * 3; rp.samples = samples - (size_t)rp.y0 * W;
+                rp.accum = reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(accum) - (uintptr_t)rp.y0 * W * 12);
+                rp.samples = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(samples) - (uintptr_t)rp.y0 * W * 4);
                 rp.spp_begin = 0; rp.spp_count = 64;
                 rp.tiles_x = (W + 7) / 8; rp.tiles_y = rows / 8;
                 rp.tile_stride = 0;
