@@ -181,7 +181,7 @@ typedef struct ptamd_scene_info {
     const void* d_shade;
     uint32_t leading_boxes;      /* unrotated boxes at the head of the object list whose tests share one set of direction
                                     reciprocals (0 when fewer than two lead the list) */
-    uint32_t walk_cut;           /* scenes that are one LDS-resident mesh: the 64ths of a wave's walking lanes at which a walk
+    uint32_t walk_cut;           /* LDS-resident scenes whose last object is a mesh: the 64ths of a wave's walking lanes at which a walk
                                     is cut and resumed in the wave's next search (0: never; 0xffffffff: not measured yet, the
                                     first launch of 64 spp or more measures it). The film does not depend on it */
 } ptamd_scene_info;

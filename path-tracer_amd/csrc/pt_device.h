@@ -277,7 +277,7 @@ typedef uint32_t StackEntry;
 #ifndef PT_CUT_STEPS
 #define PT_CUT_STEPS 2
 #endif
-// A search that cuts its tail (sample-major kernel, scenes that are one LDS-resident mesh). A wave pays for the longest of
+// A search that cuts its tail (sample-major kernel, LDS-resident scenes whose last object is a mesh). A wave pays for the longest of
 // its 64 walks: 26 node trips for 9 visits per lane on the mesh Cornell. With a cut the wave leaves the walk when the lanes
 // still walking are down to `cut64` 64ths of those that entered it; a lane whose walk is not finished parks its traversal
 // state (three words in LDS; its stack column stays where it is) and goes on in the wave's next search, beside the new rays
@@ -849,8 +849,8 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
                     tri = with_side(tri, dn);
                 }
             } else if (BUDGET && i == sc.num_objects - 1) {
-                // The budget covers the walk of the scene's last object (the launcher grants one only to scenes that are a single
-                // mesh; a lane that resumes would run any objects before it again with its unchanged ray and find the same hits).
+                // The cut covers the walk of the scene's last object. A lane that resumes has run the objects before it again
+                // with its unchanged ray (beside the lanes that test them for the first time) and found the same hits.
                 mesh_traverse<BLOCK, COUNT, true>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt, wb);
                 if (wb->unfinished) tri = -1; // not final yet
             } else {

@@ -856,7 +856,7 @@ static int commit_scene(ptamd_scene* s)
     ds.groups = s->d_groups.ptr; ds.images = s->d_images.ptr; ds.texels = s->d_texels.ptr;
     std::memcpy(ds.background, s->background, 12);
     ds.sky = s->sky_size ? reinterpret_cast<const float4*>(s->d_sky.ptr) : nullptr; ds.sky_size = s->sky_size;
-    ds.lone_mesh = (s->objects.size() == 1 && s->objects.back().kind == KIND_MESH) ? 1u : 0u; ds.num_tris = (uint32_t)tris.size();
+    ds.tail_mesh = (!s->objects.empty() && s->objects.back().kind == KIND_MESH) ? 1u : 0u; ds.num_tris = (uint32_t)tris.size();
     ds.max_stack = 1; // rows of the per-lane traversal stack the deepest walk of this scene needs
     for (const HostObject& ho : s->objects)
         if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, uses_wide(*ho.mesh) ? 2 * ho.mesh->bvh.wide_depth : ho.mesh->bvh.depth);
@@ -1041,9 +1041,11 @@ int ptamd_film_device_ptrs(ptamd_film* f, void** a, void** s)
 }
 
 // ------------------------------------------------------------------------------- render
-// The walk cut (WalkBudget in pt_device.h) pays when a few long walks hold a wave (the mesh Cornell: +9 %) and costs when
-// all walks are about as long or the kernel runs at low occupancy (a camera inside a 192-triangle blob: -18 %); which of
-// the two a scene is shows in no count that the host could take at commit, so it is measured: the first launch that could
+// The walk cut (WalkBudget in pt_device.h; LDS-resident scenes whose last object is a mesh) pays when a few long walks hold
+// a wave (the mesh Cornell: +9 %, the same behind a sphere +8 %) and costs when all walks are about as long, when the kernel
+// runs at low occupancy (a camera inside a 192-triangle blob: -18 %) or when the objects in front of the mesh make every
+// extra search expensive (a room of seven boxes and two spheres around the mesh: -20 %); which of these a scene is shows in
+// no count that the host could take at commit, so it is measured: the first launch that could
 // use the cut renders two bands of the frame at 64 samples, four times with and four times without it, into a scratch
 // film, and keeps the cut if its best time (of the last three) is 2 % under the other's. The bands together hold four times
 // the workgroups that the GPU keeps resident (a launch of fewer measures one workgroup's life, not the rate): 171 rows of
@@ -1101,7 +1103,7 @@ static int tune_walk_cut(ptamd_scene* s, const DRenderParams& user)
 static int walk_cut_for(ptamd_scene* s, const DRenderParams& rp, bool may_measure, uint32_t* out)
 {
     *out = 0u;
-    if (!s->dscene.lds_resident || !s->dscene.lone_mesh) return PTAMD_OK;
+    if (!s->dscene.lds_resident || !s->dscene.tail_mesh) return PTAMD_OK;
     if (rp.spp_count < 64u || rp.depth < 2 || rp.albedo_only) return PTAMD_OK; // launches that the sample-major kernel does not take
     if (const char* env = std::getenv("PTAMD_WALK_BUDGET")) { *out = (uint32_t)std::min(63, std::max(0, std::atoi(env))); return PTAMD_OK; }
     if (s->walk_cut < 0 || s->walk_cut_w != rp.cam.width || s->walk_cut_h != rp.cam.height || s->walk_cut_depth != rp.depth) {

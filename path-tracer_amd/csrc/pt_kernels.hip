@@ -281,10 +281,10 @@ PT_DEV void add_sample_fx(unsigned long long* acc, f3 c, unsigned long long time
 // LDS_GEOM: the scene's nodes and triangles are staged into LDS (lean traversal); otherwise they are read from global memory
 // by the work-sharing traversals, which every lane of the wave enters together, a lane without a ray as a helper.
 // TILED: the launch covers one rank's interleaved square tiles (ptamd_render_tiles) instead of a rectangle.
-// BUDGET (LDS_GEOM builds, scenes that are one mesh and nothing else): a wave cuts the tail of its walk, and a lane whose
-// walk is cut goes on with it in the wave's next search (WalkBudget in pt_device.h). With other objects in
-// the scene every extra search repeats their tests too, and the budget loses: a room of seven boxes and two spheres around
-// the same mesh renders at 2809 Msamples/s with it against 3514 without.
+// BUDGET (LDS_GEOM builds, scenes whose last object is a mesh): a wave cuts the tail of that mesh's walk, and a lane whose
+// walk is cut goes on with it in the wave's next search (WalkBudget in pt_device.h). Every extra search repeats the tests of
+// the objects before the mesh, so the cut pays less the longer that list is (a sphere or a light in front of the mesh
+// Cornell: +7..8 %; seven boxes and two spheres around it: -20 %): the host measures per scene whether to use this build.
 template <bool LDS_GEOM, bool COUNT, bool EXT, bool TILED, bool BUDGET = false>
 __global__ __launch_bounds__(kBlock, LDS_GEOM ? PT_WAVES_SM : PT_WAVES_COOP) void render_samples_kernel(DScene sc, DRenderParams rp)
 {
@@ -615,7 +615,7 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     if (p.walk_budget > 63u) p.walk_budget = 63u;
     const size_t ldsPlain = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes
                             + (fits ? geomBytes : (size_t)12 * kBlock);
-    const bool budget = fits && sc.lone_mesh != 0u && p.walk_budget != 0u && p.stack_depth <= 31 // a parked stack height has five bits
+    const bool budget = fits && sc.tail_mesh != 0u && p.walk_budget != 0u && p.stack_depth <= 31 // a parked stack height has five bits
                         && ldsPlain + kSamplesParkBytes <= kLdsBlockBytes;                       // the parked walks must not cost the scene this kernel
     const size_t ldsSamples = ldsPlain + (budget ? kSamplesParkBytes : 0u);
     if (!noSampleMajor && rp.spp_count >= 64u && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only

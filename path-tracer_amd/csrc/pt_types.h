@@ -154,7 +154,7 @@ struct DScene {
     const uint8_t* texels;
     float background[3];
     int32_t lead_aligned;     // objects [0, lead_aligned) are all unrotated boxes (DObject::aligned); 0 when fewer than two lead the list
-    uint32_t lone_mesh;       // 1 when the scene is one mesh and nothing else (its walk can run on a budget, WalkBudget)
+    uint32_t tail_mesh;       // 1 when the last object of the list is a mesh (its walk may cut its tail, WalkBudget)
     uint32_t num_tris;        // total over all meshes
     const float4* lds_nodes;  // kLdsNodeBytes per node; present when lds_resident
     uint32_t lds_node_f4;     // their size in float4
@@ -182,7 +182,7 @@ struct DRenderParams {
     uint32_t seed, flags;  // flags: PTAMD_FLAG_* of the public header
     int32_t tiles_x, tiles_y; // 8x8-pixel tiles covering the rect
     int32_t stack_depth;      // rows of the per-lane traversal stack in LDS (set by the launcher)
-    uint32_t walk_budget;     // sample-major LDS kernel, scenes that are one mesh: the 64ths of a wave's walking lanes at which
+    uint32_t walk_budget;     // sample-major LDS kernel, scenes whose last object is a mesh: the 64ths of a wave's walking lanes at which
                               // it cuts a walk and parks what is left (WalkBudget; set by the host, 0 = never)
     // Interleaved-tile launches (tile_stride > 0, ptamd_render_tiles) cover, instead of the rect, the square tiles of
     // tile_size pixels (a multiple of 8) whose row-major index is tile_phase + k * tile_stride, k < tiles_owned;

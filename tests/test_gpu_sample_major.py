@@ -131,11 +131,12 @@ def test_sample_major_tiles_from_lds(gpu):
 
 @pytest.mark.parametrize("name", ["mesh_cornell", "two_meshes"])
 def test_walk_cut_changes_the_schedule_not_the_film(gpu, name, monkeypatch):
-    """In a scene that is one mesh staged in LDS, the sample-major kernel can cut a wave's walk when few of its lanes are
-    still walking and let the unfinished lanes go on in the wave's next search. A lane's walk is the same sequence of steps
-    wherever it is cut, so the film, the ray total and the per-lane work must be bit-identical without the cut
-    (PTAMD_WALK_BUDGET=0), with the usual one (24 of 64 lanes) and with one so eager that most walks are cut many times; only
-    the wave-level trip counts may move. `two_meshes`: a scene with a second object is never cut whatever the variable says."""
+    """In an LDS-resident scene whose last object is a mesh, the sample-major kernel can cut a wave's walk of that mesh when
+    few of its lanes are still walking and let the unfinished lanes go on in the wave's next search. A lane's walk is the
+    same sequence of steps wherever it is cut, so the film, the ray total and the shaded hits must be bit-identical without
+    the cut (PTAMD_WALK_BUDGET=0), with the usual one (24 of 64 lanes) and with one so eager that most walks are cut many
+    times; only the wave-level trip counts may move. `two_meshes`: a lane that resumes walks the mesh in front of the last
+    one again (more lane-level work, the same hits)."""
     if name == "mesh_cornell":
         scene = presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 56)
     else:
@@ -154,14 +155,14 @@ def test_walk_cut_changes_the_schedule_not_the_film(gpu, name, monkeypatch):
         stats.append(gpu.RenderStats())
     for f, s in zip(films[1:], stats[1:]):
         assert np.array_equal(films[0].view(np.uint32), f.view(np.uint32))
-        for k in ("samples", "rays", "nodes", "tris", "shade_lanes"):
+        for k in ("samples", "rays", "shade_lanes"):
             assert s[k] == stats[0][k], (k, s[k], stats[0][k])
+        for k in ("nodes", "tris"):
+            assert s[k] == stats[0][k] if name == "mesh_cornell" else s[k] >= stats[0][k], (k, s[k], stats[0][k])
     assert float(films[0].mean()) > 0.5
     if name == "mesh_cornell":  # the cut packs the node loop: fewer wave-level node trips for the same lane-level visits
         assert stats[1]["node_trips"] < 0.8 * stats[0]["node_trips"], (stats[1]["node_trips"], stats[0]["node_trips"])
         assert stats[2]["ray_trips"] > stats[1]["ray_trips"] > stats[0]["ray_trips"]
-    else:
-        assert stats[1]["node_trips"] == stats[0]["node_trips"]
 
 
 def test_walk_cut_is_measured_once_per_commit_and_leaves_the_film_alone(gpu, monkeypatch):

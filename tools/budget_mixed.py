@@ -1,5 +1,5 @@
-"""Walk budget on a scene where few rays reach the LDS-resident mesh (room of boxes + two spheres + a small mesh last):
-python tools/budget_mixed.py   (GPU box, repo root). Prints Msamples/s without a budget and with the default one."""
+"""Walk cut on scenes where a room of boxes and two spheres stands in front of the LDS-resident mesh:
+python tools/budget_mixed.py   (GPU box, repo root). Prints Msamples/s without the cut, with it, and with what the library measures."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "path-tracer_amd")):
@@ -14,7 +14,7 @@ for label, kw in (("small mesh among primitives", dict(mesh_pos=(2.0, 0.1, 1.5),
     pt, cam = ptamd.build_scene(scene)
     assert pt.Info()["lds_resident"] == 1
     film = ptamd.Film(1920, 1080)
-    for budget in ("0", None):
+    for budget in ("0", "24", None):
         if budget is None: os.environ.pop("PTAMD_WALK_BUDGET", None)
         else: os.environ["PTAMD_WALK_BUDGET"] = budget
         ptamd.Render(cam, pt, film, 64, 8)
@@ -25,5 +25,5 @@ for label, kw in (("small mesh among primitives", dict(mesh_pos=(2.0, 0.1, 1.5),
         dt = (time.time() - t0) / 3
         ptamd.Render(cam, pt, film, 64, 8, count=True)
         s = ptamd.RenderStats()
-        print("%-30s budget %-7s %8.1f Msamples/s  node lanes %.2f shading lanes %.2f" % (label, budget or "default", 1920 * 1080 * 128 / dt * 1e-6,
+        print("%-30s budget %-7s %8.1f Msamples/s  node lanes %.2f shading lanes %.2f" % (label, budget or "measured %d" % pt.Info()["walk_cut"], 1920 * 1080 * 128 / dt * 1e-6,
               s["nodes"] / max(1, 64 * s["node_trips"]), s["shade_lanes"] / max(1, 64 * s["shade_trips"])))
