@@ -1108,7 +1108,7 @@ static int walk_cut_for(ptamd_scene* s, const DRenderParams& rp, bool may_measur
     if (const char* env = std::getenv("PTAMD_WALK_BUDGET")) { *out = (uint32_t)std::min(63, std::max(0, std::atoi(env))); return PTAMD_OK; }
     if (s->walk_cut < 0 || s->walk_cut_w != rp.cam.width || s->walk_cut_h != rp.cam.height || s->walk_cut_depth != rp.depth) {
         if (!may_measure) return PTAMD_OK;
-        if (int rc = tune_walk_cut(s, rp)) return rc;
+        if (tune_walk_cut(s, rp) != PTAMD_OK) { (void)hipGetLastError(); s->walk_cut = 0; } // no scratch film: render without the cut
     }
     *out = (uint32_t)s->walk_cut;
     return PTAMD_OK;
