@@ -764,11 +764,63 @@ PT_DEV int mesh_traverse_wide(const DScene& sc, const DMesh& me, bool valid, f3 
     return (int)(uint32_t)best - 1;
 }
 
+// One mesh object of the closest-hit loop through the work-sharing walks (Mesh::Hit, Mesh.cpp:57-77, 249): every lane of the
+// wave makes the call together; a lane that does not want an answer (`wants` false) enters without a ray and takes over
+// pending subtrees of the others. A closer hit replaces `best`.
+template <int BLOCK, bool COUNT>
+PT_DEV void shared_walk_hit(const DScene& sc, const Geom& geom, const DObject& ob, const Ray& ray, bool wants, Best& best,
+                            StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts& cnt)
+{
+    const DMesh& me = sc.meshes[ob.mesh];
+    const bool identity = (me.flags & 8u) != 0u; // wave-uniform: multiplying by the identity returns its argument exactly
+    f3 oo = identity ? ray.o : xform_point(me.minv, ray.o);
+    f3 dd = identity ? ray.d : xform_dir(me.minv, ray.d);
+    float len2 = dot(dd, dd);
+    const bool valid = len2 != 0.0f && wants; // Mesh.cpp:64
+    float dirLen = fsqrt(len2);
+    float invLen = frcp(dirLen);
+    dd = dd * invLen;
+    float tMinObj = 1e-4f * dirLen;
+    float closestT = best.t * dirLen;      // Mesh.cpp:72-75
+    float u = 0.f, v = 0.f;
+    int tri = (me.flags & 4u) ? mesh_traverse_wide<BLOCK, COUNT>(sc, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt)
+                              : mesh_traverse_coop<BLOCK, COUNT>(sc, geom, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt);
+    if (!valid) tri = -1;
+    if (tri >= 0) { // the winner's own record, this lane's own ray
+        float dn;
+        tri_uv(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, oo, dd, u, v, dn);
+        tri = with_side(tri, dn);
+        float tW = closestT * invLen;      // Mesh.cpp:249
+        if (tW < best.t) { best.t = tW; best.obj = kMeshHit | ob.mesh; best.tri = tri + (int)me.tri_base; best.u = u; best.v = v; }
+    }
+}
+
+// Does the ray meet the bounds of the scene's last object, a mesh, in front of the hit at tMax? In the mesh's own frame with
+// the direction as transformed (not normalised: its parameter is the world one); the box of the positions comes padded from
+// the host in DObject::c / half, and every doubtful case answers yes.
+PT_DEV bool meets_tail_mesh(const DScene& sc, const Ray& ray, float tMax)
+{
+    const DObject& ob = sc.objects[sc.num_objects - 1];
+    const DMesh& me = sc.meshes[ob.mesh];
+    const bool identity = (me.flags & 8u) != 0u;
+    const f3 oo = identity ? ray.o : xform_point(me.minv, ray.o);
+    const f3 dd = identity ? ray.d : xform_dir(me.minv, ray.d);
+    const float BIG = 1e30f;
+    const f3 inv = mk3(dd.x != 0.0f ? frcp(dd.x) : BIG, dd.y != 0.0f ? frcp(dd.y) : BIG, dd.z != 0.0f ? frcp(dd.z) : BIG);
+    const f3 ro = oo - mk3(ob.c[0], ob.c[1], ob.c[2]);
+    const f3 he = mk3(ob.half[0], ob.half[1], ob.half[2]);
+    const f3 t1 = (-he - ro) * inv, t2 = (he - ro) * inv;
+    const float tEntry = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fminf(t1.z, t2.z));
+    const float tExit = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1.z, t2.z));
+    return !(tExit < tEntry) & !(tExit < 0.0f) & !(tEntry > tMax * 1.0001f);
+}
+
 // Closest-hit loop of PathTracer::TraceRay (PathTracer.cpp:38-57) over the flat object list. COOP selects the
 // work-sharing traversal (every lane of the wave must then make the call together). `helper` (COOP only): this lane
 // needs no answer of its own (its result is discarded by the caller); it enters the meshes without a ray and takes
-// over pending subtrees of the other lanes.
-template <int BLOCK, bool COUNT, bool COOP, bool BUDGET = false>
+// over pending subtrees of the other lanes. PRIMS: every object but the last (a scene whose only mesh is its last object:
+// the caller runs that walk itself, shared_walk_hit).
+template <int BLOCK, bool COUNT, bool COOP, bool BUDGET = false, bool PRIMS = false>
 PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, StackEntry* __restrict__ stack, const Coop& coop, int slot, TraversalCounts* counts = nullptr, bool helper = false,
                         WalkBudget* wb = nullptr)
 {
@@ -817,7 +869,8 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
         }
     }
 #endif
-    for (; i < sc.num_objects; ++i) {
+    const int numObjects = PRIMS ? sc.num_objects - 1 : sc.num_objects;
+    for (; i < numObjects; ++i) {
         const DObject& ob = sc.objects[i];
         if (ob.kind == KIND_SPHERE) {
             float t = sphere_t(ob, ray, kTMin, best.t);
@@ -825,30 +878,22 @@ PT_DEV Best closest_hit(const DScene& sc, const Geom& geom, const Ray& ray, Stac
         } else if (ob.kind == KIND_BOX) {
             float t = box_t(ob, ray, kTMin, best.t);
             if (t >= 0.0f && t < best.t) { best.t = t; best.obj = i; }
-        } else {
+        } else if (COOP) {
+            shared_walk_hit<BLOCK, COUNT>(sc, geom, ob, ray, !helper, best, stack, coop, slot, cnt);
+        } else if (!PRIMS) {
             const DMesh& me = sc.meshes[ob.mesh];
             const bool identity = (me.flags & 8u) != 0u; // wave-uniform: multiplying by the identity returns its argument exactly
             f3 oo = identity ? ray.o : xform_point(me.minv, ray.o);
             f3 dd = identity ? ray.d : xform_dir(me.minv, ray.d);
             float len2 = dot(dd, dd);
-            const bool valid = len2 != 0.0f && !(COOP && helper); // Mesh.cpp:64
-            if (!COOP && !valid) continue;
+            if (len2 == 0.0f) continue; // Mesh.cpp:64
             float dirLen = fsqrt(len2);
             float invLen = frcp(dirLen);
             dd = dd * invLen;
             float tMinObj = kTMin * dirLen;
             float closestT = best.t * dirLen;      // Mesh.cpp:72-75
             int tri = -1; float u = 0.f, v = 0.f;
-            if (COOP) {
-                tri = (me.flags & 4u) ? mesh_traverse_wide<BLOCK, COUNT>(sc, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt)
-                                      : mesh_traverse_coop<BLOCK, COUNT>(sc, geom, me, valid, oo, dd, tMinObj, closestT, stack, coop, slot, cnt);
-                if (!valid) tri = -1;
-                if (tri >= 0) { // the winner's own record, this lane's own ray
-                    float dn;
-                    tri_uv(sc.tris + ((size_t)me.tri_base + (size_t)tri) * 3, oo, dd, u, v, dn);
-                    tri = with_side(tri, dn);
-                }
-            } else if (BUDGET && i == sc.num_objects - 1) {
+            if (BUDGET && i == sc.num_objects - 1) {
                 // The cut covers the walk of the scene's last object. A lane that resumes has run the objects before it again
                 // with its unchanged ray (beside the lanes that test them for the first time) and found the same hits.
                 mesh_traverse<BLOCK, COUNT, true>(sc, geom, me, oo, dd, tMinObj, closestT, tri, u, v, stack, slot, cnt, wb);

@@ -822,6 +822,12 @@ static int commit_scene(ptamd_scene* s)
             dm.node_base = ms.node_base; dm.tri_base = ms.tri_base; dm.group_base = ms.group_base; dm.image_base = ms.image_base;
             dm.num_tris = md.num_faces(); dm.root = wide ? 0 : hm.bvh.root; dm.flags = ms.flags;
             fill_mesh_matrices(ho, dm);
+            // the box of the mesh's positions in its own frame, a little larger (pt_device.h: meets_tail_mesh)
+            for (int k = 0; k < 3; ++k) {
+                const float lo = hm.bmin[k], hi = hm.bmax[k];
+                d.c[k] = 0.5f * lo + 0.5f * hi;
+                d.half[k] = lo <= hi ? (0.5f * hi - 0.5f * lo) * 1.0002f + 1e-4f * std::max(std::fabs(lo), std::fabs(hi)) + 1e-30f : -1.0f;
+            }
             d.mesh = (int32_t)meshes.size();
             meshes.push_back(dm);
         }
@@ -857,6 +863,7 @@ static int commit_scene(ptamd_scene* s)
     std::memcpy(ds.background, s->background, 12);
     ds.sky = s->sky_size ? reinterpret_cast<const float4*>(s->d_sky.ptr) : nullptr; ds.sky_size = s->sky_size;
     ds.tail_mesh = (!s->objects.empty() && s->objects.back().kind == KIND_MESH) ? 1u : 0u; ds.num_tris = (uint32_t)tris.size();
+    if (ds.tail_mesh && meshes.size() == 1) ds.tail_mesh |= 2u; // ... and it is the scene's only mesh
     ds.max_stack = 1; // rows of the per-lane traversal stack the deepest walk of this scene needs
     for (const HostObject& ho : s->objects)
         if (ho.kind == KIND_MESH) ds.max_stack = std::max(ds.max_stack, uses_wide(*ho.mesh) ? 2 * ho.mesh->bvh.wide_depth : ho.mesh->bvh.depth);
@@ -1041,74 +1048,93 @@ int ptamd_film_device_ptrs(ptamd_film* f, void** a, void** s)
 }
 
 // ------------------------------------------------------------------------------- render
-// The walk cut (WalkBudget in pt_device.h; LDS-resident scenes whose last object is a mesh) pays when a few long walks hold
-// a wave (the mesh Cornell: +9 %, the same behind a sphere +8 %) and costs when all walks are about as long, when the kernel
-// runs at low occupancy (a camera inside a 192-triangle blob: -18 %) or when the objects in front of the mesh make every
-// extra search expensive (a room of seven boxes and two spheres around the mesh: -20 %); which of these a scene is shows in
-// no count that the host could take at commit, so it is measured: the first launch that could
-// use the cut renders two bands of the frame at 64 samples, four times with and four times without it, into a scratch
-// film, and keeps the cut if its best time (of the last three) is 2 % under the other's. The bands together hold four times
-// the workgroups that the GPU keeps resident (a launch of fewer measures one workgroup's life, not the rate): 171 rows of
-// a 1080p frame, about 50 ms in all, once per commit and (film size, depth). The film does not depend on the choice.
-// PTAMD_WALK_BUDGET=<0..63> sets it without measuring.
+// Two schedules of the sample-major kernel leave the film as it is and pay on some scenes only, so the first launch that
+// could use one measures it (DRenderParams::walk_budget carries the choice):
+//  * the walk cut (WalkBudget in pt_device.h; LDS-resident scenes whose last object is a mesh) pays when a few long walks
+//    hold a wave (the mesh Cornell: +9 %, the same behind a sphere +8 %) and costs when all walks are about as long, when
+//    the kernel runs at low occupancy (a camera inside a 192-triangle blob: -18 %) or when the objects in front of the mesh
+//    make every extra search expensive (a room of seven boxes and two spheres around the mesh: -20 %);
+//  * the deferred shared walk (DEFER in render_samples_kernel; scenes read from global memory whose only mesh is their last
+//    object): the lanes whose rays meet the mesh's bounds wait until 20 or 40 of them make the walk worth its trips. A
+//    7680-triangle mesh among primitives: +28 % at 20 lanes, +27 % at 24, +17 % at 12; a million triangles that most rays
+//    reach: -0.6 % at 24, +3.6 % at 40, +0.8 % at 48, -7 % at 56.
+// Which of these a scene is shows in no count that the host could take at commit, so the first eligible launch renders a
+// sample of the frame at 64 samples into a scratch film -- every n-th 16x16-pixel tile, four times the workgroups that the
+// GPU keeps resident in all (a launch of fewer measures one workgroup's life, not the rate) -- once to warm the caches and
+// then three times per candidate, and keeps the fastest candidate if its best time is 1.5 % under that of the plain
+// schedule: 50 to 250 ms in all, once per commit and (film size, depth). Films of under two such samples, or of more than
+// 64 Mpixels (the scratch film), are rendered with the plain schedule.
+// PTAMD_WALK_BUDGET=<0..63> (the cut) and PTAMD_WALK_DEFER=<0..64> (the waiting lanes) set them without measuring.
 constexpr uint32_t kWalkCut = 24; // of 64: cut when the lanes still walking are down to 3/8 of those that entered the walk
+constexpr uint32_t kDeferFew = 20, kDeferMany = 40; // waiting lanes that start a deferred walk
 static int tune_walk_cut(ptamd_scene* s, const DRenderParams& user)
 {
     const int W = user.cam.width, H = user.cam.height;
     s->walk_cut_w = W; s->walk_cut_h = H; s->walk_cut_depth = user.depth;
     s->walk_cut = 0;
-    const long long kProbeBlocks = 4 * 1280; // 8x8-pixel workgroups: four times 256 CUs x 5 resident workgroups
-    const int blocksPerStrip = (W + 7) / 8;
-    int rows = (int)((kProbeBlocks + blocksPerStrip - 1) / blocksPerStrip) * 8; // both bands together
-    rows = ((rows + 15) / 16) * 16 / 2;                                         // one band, a multiple of 8
-    if (3 * rows > H) return PTAMD_OK; // a film of fewer workgroups than that: not worth the launches
+    const bool defer = !s->dscene.lds_resident;
+    const uint32_t cand[3] = { 0u, defer ? kDeferFew : kWalkCut, kDeferMany };
+    const int ncand = defer ? 3 : 2;
+    const int kTile = 16;                          // pixels: four 8x8-pixel workgroups
+    const long long kProbeTiles = 4 * 1280 / 4;    // four times 256 CUs x 5 resident workgroups
+    const int cols = (W + kTile - 1) / kTile;
+    const long long total = (long long)cols * ((H + kTile - 1) / kTile);
+    if (total < 2 * kProbeTiles || (long long)W * H > (64ll << 20)) return PTAMD_OK;
+    int stride = (int)(total / kProbeTiles);
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    while (gcd(stride, cols) != 1) ++stride; // the sampled tiles fall in every column of tiles, not in a few
     float* accum = nullptr; uint32_t* samples = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() { if (accum) (void)hipFree(accum); if (samples) (void)hipFree(samples); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
     auto bail = [&](hipError_t e) { cleanup(); return fail(PTAMD_ERR_DEVICE, hipGetErrorString(e)); };
     hipError_t e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&accum), (size_t)W * rows * 12)) != hipSuccess) return bail(e);
-    if ((e = hipMalloc(reinterpret_cast<void**>(&samples), (size_t)W * rows * 4)) != hipSuccess) return bail(e);
-    if ((e = hipMemsetAsync(accum, 0, (size_t)W * rows * 12, g_stream)) != hipSuccess) return bail(e);
-    if ((e = hipMemsetAsync(samples, 0, (size_t)W * rows * 4, g_stream)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&accum), (size_t)W * H * 12)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&samples), (size_t)W * H * 4)) != hipSuccess) return bail(e);
+    if ((e = hipMemsetAsync(accum, 0, (size_t)W * H * 12, g_stream)) != hipSuccess) return bail(e);
+    if ((e = hipMemsetAsync(samples, 0, (size_t)W * H * 4, g_stream)) != hipSuccess) return bail(e);
     if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) return bail(e);
-    float best[2] = { 3.0e38f, 3.0e38f };
+    DRenderParams rp = user;
+    rp.counters = nullptr; rp.flags &= ~(uint32_t)PTAMD_FLAG_COUNT;
+    rp.accum = accum; rp.samples = samples;
+    rp.x0 = 0; rp.y0 = 0; rp.x1 = W; rp.y1 = H; rp.tiles_x = (W + 7) / 8; rp.tiles_y = (H + 7) / 8;
+    rp.spp_begin = 0; rp.spp_count = 64;
+    rp.tile_size = kTile; rp.tile_phase = stride / 2; rp.tile_stride = stride; rp.tile_cols = cols;
+    rp.tile_side = kTile / 8; rp.tile_waves = rp.tile_side * rp.tile_side;
+    rp.tiles_owned = (int)((total - rp.tile_phase + stride - 1) / stride);
+    float best[3] = { 3.0e38f, 3.0e38f, 3.0e38f };
     for (int rep = 0; rep < 4; ++rep) // the first pass warms the caches and is not timed
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < (rep ? ncand : 1); ++v) {
+            rp.walk_budget = cand[v];
             if ((e = hipEventRecord(e0, g_stream)) != hipSuccess) return bail(e);
-            for (int band = 1; band <= 2; ++band) {
-                DRenderParams rp = user;
-                rp.counters = nullptr; rp.flags &= ~(uint32_t)PTAMD_FLAG_COUNT;
-                rp.x0 = 0; rp.x1 = W; rp.y0 = band * H / 3 - rows / 2; rp.y1 = rp.y0 + rows;
-                // the band's first row is row 0 of the scratch film (the kernel addresses pixels as y * W + x)
-                rp.accum = reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(accum) - (uintptr_t)rp.y0 * W * 12);
-                rp.samples = reinterpret_cast<uint32_t*>(reinterpret_cast<uintptr_t>(samples) - (uintptr_t)rp.y0 * W * 4);
-                rp.spp_begin = 0; rp.spp_count = 64;
-                rp.tiles_x = (W + 7) / 8; rp.tiles_y = rows / 8;
-                rp.tile_stride = 0;
-                rp.walk_budget = v ? kWalkCut : 0u;
-                if ((e = launch_render(s->dscene, rp, g_stream)) != hipSuccess) return bail(e);
-            }
+            if ((e = launch_render(s->dscene, rp, g_stream)) != hipSuccess) return bail(e);
             if ((e = hipEventRecord(e1, g_stream)) != hipSuccess || (e = hipEventSynchronize(e1)) != hipSuccess) return bail(e);
             float ms = 0.0f;
             if ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) return bail(e);
             if (rep > 0) best[v] = std::min(best[v], ms);
         }
     cleanup();
-    s->walk_cut = best[1] < 0.98f * best[0] ? (int)kWalkCut : 0;
-    if (std::getenv("PTAMD_DEBUG")) std::fprintf(stderr, "ptamd: walk cut measured: %.3f ms without, %.3f ms with -> %d/64\n", best[0], best[1], s->walk_cut);
+    int pick = 0;
+    for (int v = 1; v < ncand; ++v) if (best[v] < best[pick]) pick = v;
+    s->walk_cut = best[pick] < 0.985f * best[0] ? (int)cand[pick] : 0;
+    if (std::getenv("PTAMD_DEBUG")) {
+        std::fprintf(stderr, "ptamd: %s measured on %d tiles:", defer ? "deferred walk" : "walk cut", rp.tiles_owned);
+        for (int v = 0; v < ncand; ++v) std::fprintf(stderr, " %u: %.3f ms", cand[v], best[v]);
+        std::fprintf(stderr, " -> %d\n", s->walk_cut);
+    }
     return PTAMD_OK;
 }
-// The cut for this launch (DRenderParams::walk_budget). may_measure: the caller may allocate (the scratch film).
+// The schedule for this launch (DRenderParams::walk_budget). may_measure: the caller may allocate (the scratch film).
 static int walk_cut_for(ptamd_scene* s, const DRenderParams& rp, bool may_measure, uint32_t* out)
 {
     *out = 0u;
-    if (!s->dscene.lds_resident || !s->dscene.tail_mesh) return PTAMD_OK;
+    const bool cut = s->dscene.lds_resident && s->dscene.tail_mesh;
+    const bool defer = !s->dscene.lds_resident && (s->dscene.tail_mesh & 2u);
+    if (!cut && !defer) return PTAMD_OK;
     if (rp.spp_count < 64u || rp.depth < 2 || rp.albedo_only) return PTAMD_OK; // launches that the sample-major kernel does not take
-    if (const char* env = std::getenv("PTAMD_WALK_BUDGET")) { *out = (uint32_t)std::min(63, std::max(0, std::atoi(env))); return PTAMD_OK; }
+    if (const char* env = std::getenv(cut ? "PTAMD_WALK_BUDGET" : "PTAMD_WALK_DEFER")) { *out = (uint32_t)std::min(cut ? 63 : 64, std::max(0, std::atoi(env))); return PTAMD_OK; }
     if (s->walk_cut < 0 || s->walk_cut_w != rp.cam.width || s->walk_cut_h != rp.cam.height || s->walk_cut_depth != rp.depth) {
         if (!may_measure) return PTAMD_OK;
-        if (tune_walk_cut(s, rp) != PTAMD_OK) { (void)hipGetLastError(); s->walk_cut = 0; } // no scratch film: render without the cut
+        if (tune_walk_cut(s, rp) != PTAMD_OK) { (void)hipGetLastError(); s->walk_cut = 0; } // no scratch film: render with the plain schedule
     }
     *out = (uint32_t)s->walk_cut;
     return PTAMD_OK;

@@ -27,8 +27,9 @@ struct DMaterial {
 struct DObject {
     int32_t kind, material, mesh;
     int32_t aligned;                // box whose axes are the world axes (no rotation): its local ray is origin - centre, direction
-    float c[3]; float radius;       // sphere/box centre; sphere radius
-    float half[3]; float eps;       // box half extents; face epsilon = 1e-4 * max half extent (Box.cpp:63)
+    float c[3]; float radius;       // sphere/box centre; sphere radius. Mesh: centre of the box of its positions in its own frame
+    float half[3]; float eps;       // box half extents; face epsilon = 1e-4 * max half extent (Box.cpp:63). Mesh: half extents of that
+                                    // box, padded (negative when the mesh has no finite position)
     float ax0[3]; float pad1;       // box axes = columns of worldFromLocal (Box.cpp:16-23)
     float ax1[3]; float pad2;
     float ax2[3]; float pad3;
@@ -154,7 +155,8 @@ struct DScene {
     const uint8_t* texels;
     float background[3];
     int32_t lead_aligned;     // objects [0, lead_aligned) are all unrotated boxes (DObject::aligned); 0 when fewer than two lead the list
-    uint32_t tail_mesh;       // 1 when the last object of the list is a mesh (its walk may cut its tail, WalkBudget)
+    uint32_t tail_mesh;       // bit 0: the last object of the list is a mesh (its walk may cut its tail, WalkBudget); bit 1: it is the
+                              // scene's only mesh (read from global memory, its shared walk may wait for more rays)
     uint32_t num_tris;        // total over all meshes
     const float4* lds_nodes;  // kLdsNodeBytes per node; present when lds_resident
     uint32_t lds_node_f4;     // their size in float4
@@ -183,7 +185,9 @@ struct DRenderParams {
     int32_t tiles_x, tiles_y; // 8x8-pixel tiles covering the rect
     int32_t stack_depth;      // rows of the per-lane traversal stack in LDS (set by the launcher)
     uint32_t walk_budget;     // sample-major LDS kernel, scenes whose last object is a mesh: the 64ths of a wave's walking lanes at which
-                              // it cuts a walk and parks what is left (WalkBudget; set by the host, 0 = never)
+                              // it cuts a walk and parks what is left (WalkBudget; set by the host, 0 = never). Global-memory scenes
+                              // whose only mesh is their last object: the lanes (1..64) that wait at its bounds before the wave
+                              // walks it (0 = every search walks it)
     // Interleaved-tile launches (tile_stride > 0, ptamd_render_tiles) cover, instead of the rect, the square tiles of
     // tile_size pixels (a multiple of 8) whose row-major index is tile_phase + k * tile_stride, k < tiles_owned;
     // tile_cols tiles per film row, tile_side = tile_size / 8 wave-tiles per tile row, tile_waves = tile_side^2.

@@ -196,3 +196,81 @@ def test_walk_cut_is_measured_once_per_commit_and_leaves_the_film_alone(gpu, mon
     small, cam_s = gpu.build_scene(presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 56))
     gpu.Render(cam_s, small, gpu.Film(96, 56), 64, 8, seed=3)
     assert small.Info()["walk_cut"] == 0            # a small film: not worth the launches
+
+
+def mixed_blob(w, h):
+    return presets.mixed("tests/golden/blob.glb", w, h, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
+
+
+@pytest.mark.parametrize("name", ["blob_among_primitives", "roulette_sky_tiles", "dragon_field_wide_nodes"])
+def test_deferred_walk_changes_the_schedule_not_the_film(gpu, name, monkeypatch, dragon_field_glb):
+    """A scene read from global memory whose only mesh is its last object: the sample-major kernel can let the lanes whose
+    rays meet the mesh's bounds wait until enough of them make the shared walk worth its trips (PTAMD_WALK_DEFER = the
+    number of waiting lanes that starts a walk; 0 = every search walks the mesh, as before). A ray's closest hit does not
+    depend on when its walk runs or on how many rays walk beside it (ties go to the lower triangle index), so the film, the
+    ray total and the shaded hits must be bit-identical for every threshold: 1 = the bounds test alone decides who walks,
+    20 and 40 = the values the host chooses between, 64 = a walk only when every lane of the wave waits or has nothing else
+    to do. Node visits fall (rays that miss the bounds no longer enter, helpers speculate less); triangle tests depend on
+    the order in which a wave finds its hits and may move by a little either way."""
+    rr, tiles = False, None
+    if name == "blob_among_primitives":
+        scene, (w, h), spp = mixed_blob(160, 96), (160, 96), 70
+    elif name == "roulette_sky_tiles":
+        scene = dict(mixed_blob(128, 96), skybox={"faces": gradient_faces(16, seed=2), "intensity": 1.1})
+        scene["objects"] = scene["objects"][:4] + scene["objects"][5:]  # a wall less: paths reach the sky
+        (w, h), spp, rr, tiles = (128, 96), 64, True, 2
+    else:
+        from scenes import dragon
+        scene, (w, h), spp = dragon.config3_scene(dragon_field_glb, 96, 54), (96, 54), 64
+    pt, cam = gpu.build_scene(scene)
+    info = pt.Info()
+    assert info["lds_resident"] == 0 and (info["wide_nodes"] > 0) == (name == "dragon_field_wide_nodes")
+    films, stats = [], []
+    for lanes in ("0", "1", "20", "40", "64"):
+        monkeypatch.setenv("PTAMD_WALK_DEFER", lanes)
+        f = gpu.Film(w, h)
+        tot = {}
+        for rank in range(tiles or 1):
+            gpu.Render(cam, pt, f, spp, 8, seed=11, count=True, russian_roulette=rr, tiles=(16, rank, tiles) if tiles else None)
+            for k, v in gpu.RenderStats().items():
+                tot[k] = tot.get(k, 0) + v
+        assert (f.Samples() == spp).all()
+        films.append(f.Accum())
+        stats.append(tot)
+    for f, s in zip(films[1:], stats[1:]):
+        assert np.array_equal(films[0].view(np.uint32), f.view(np.uint32))
+        for k in ("samples", "rays", "shade_lanes"):
+            assert s[k] == stats[0][k], (k, s[k], stats[0][k])
+        assert s["nodes"] <= stats[0]["nodes"] and s["tris"] <= 1.01 * stats[0]["tris"]
+    assert float(films[0].mean()) > 0.05
+    if name == "blob_among_primitives":  # fuller walks: fewer wave-level node trips and steal rounds for the mesh
+        assert stats[2]["node_trips"] < 0.75 * stats[0]["node_trips"], (stats[2]["node_trips"], stats[0]["node_trips"])
+        assert stats[2]["steal_rounds"] < stats[0]["steal_rounds"]
+        assert stats[4]["ray_trips"] > stats[2]["ray_trips"] > stats[0]["ray_trips"]  # ... for more trips of the bounce loop
+
+
+def test_deferred_walk_is_chosen_by_measurement(gpu, monkeypatch):
+    """Without the variable the first launch of 64 samples and more on such a scene measures the plain schedule against
+    walks deferred until 20 and until 40 lanes wait and keeps the fastest (ptamd_scene_info.walk_cut), once per commit; a
+    scene with a second mesh has no deferred walk to choose."""
+    monkeypatch.delenv("PTAMD_WALK_DEFER", raising=False)
+    scene = mixed_blob(1280, 720)
+    pt, cam = gpu.build_scene(scene)
+    unknown = 0xffffffff
+    assert pt.Info()["lds_resident"] == 0 and pt.Info()["walk_cut"] == unknown
+    a = gpu.Film(1280, 720)
+    gpu.Render(cam, pt, a, 64, 8, seed=3)
+    chosen = pt.Info()["walk_cut"]
+    assert chosen in (0, 20, 40)
+    print("deferred walk chosen for the blob among primitives at 1280x720:", chosen)
+    monkeypatch.setenv("PTAMD_WALK_DEFER", "0" if chosen else "20")
+    b = gpu.Film(1280, 720)
+    gpu.Render(cam, pt, b, 64, 8, seed=3)           # another choice: same film
+    assert np.array_equal(a.Accum().view(np.uint32), b.Accum().view(np.uint32))
+    assert pt.Info()["walk_cut"] == chosen
+    monkeypatch.delenv("PTAMD_WALK_DEFER")
+    two = mixed_blob(1280, 720)
+    two["objects"].append(dict(two["objects"][-1], pos=(1.2, 1.0, 3.4)))
+    pt2, cam2 = gpu.build_scene(two)
+    gpu.Render(cam2, pt2, gpu.Film(1280, 720), 64, 8, seed=3)
+    assert pt2.Info()["walk_cut"] == unknown        # nothing to measure: every search walks both meshes
