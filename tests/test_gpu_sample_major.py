@@ -202,7 +202,7 @@ def mixed_blob(w, h):
     return presets.mixed("tests/golden/blob.glb", w, h, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
 
 
-@pytest.mark.parametrize("name", ["blob_among_primitives", "roulette_sky_tiles", "dragon_field_wide_nodes"])
+@pytest.mark.parametrize("name", ["blob_among_primitives", "roulette_sky_tiles", "textured_alpha_mask", "dragon_field_wide_nodes"])
 def test_deferred_walk_changes_the_schedule_not_the_film(gpu, name, monkeypatch, dragon_field_glb):
     """A scene read from global memory whose only mesh is its last object: the sample-major kernel can let the lanes whose
     rays meet the mesh's bounds wait until enough of them make the shared walk worth its trips (PTAMD_WALK_DEFER = the
@@ -219,6 +219,9 @@ def test_deferred_walk_changes_the_schedule_not_the_film(gpu, name, monkeypatch,
         scene = dict(mixed_blob(128, 96), skybox={"faces": gradient_faces(16, seed=2), "intensity": 1.1})
         scene["objects"] = scene["objects"][:4] + scene["objects"][5:]  # a wall less: paths reach the sky
         (w, h), spp, rr, tiles = (128, 96), 64, True, 2
+    elif name == "textured_alpha_mask":  # the walk's own alpha test (Mesh.cpp:196-233) and the textured hit fill behind a deferred walk
+        scene = presets.mixed("tests/golden/textured.glb", 96, 96, mesh_pos=(2.7, 1.6, 2.6), mesh_rot=(0.0, 25.0, 0.0), mesh_scale=(1.6, 1.6, 1.6))
+        (w, h), spp = (96, 96), 64
     else:
         from scenes import dragon
         scene, (w, h), spp = dragon.config3_scene(dragon_field_glb, 96, 54), (96, 54), 64
