@@ -104,9 +104,10 @@ struct ptamd_scene {
     DevBuf<DImage> d_images; DevBuf<uint8_t> d_texels;
     DevBuf<float> d_sky; int sky_size = 0;
     unsigned long long* d_counters = nullptr; // this scene's PTAMD_FLAG_COUNT tallies (allocated by its first counting render)
-    // Walk cut of the sample-major LDS kernel (scenes that are one mesh): -1 = not measured yet for (film size, depth); else
-    // the 64ths of a wave's walking lanes at which a walk is cut, 0 = never. Measured at the first eligible launch after a
-    // commit (tune_walk_cut).
+    // Schedule of the sample-major kernel for this scene's mesh walks (DRenderParams::walk_budget): -1 = not measured yet for
+    // (film size, depth); LDS-resident scenes: the 64ths of a wave's walking lanes at which a walk is cut; scenes read from
+    // global memory: the waiting lanes that start a deferred shared walk; 0 = the plain schedule. Measured at the first
+    // eligible launch after a commit (tune_walk_cut).
     int walk_cut = -1, walk_cut_w = 0, walk_cut_h = 0, walk_cut_depth = 0;
     DScene dscene;
     void release() // what commit rebuilds; the sky map is uploaded by its own call and outlives commits
