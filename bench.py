@@ -281,6 +281,14 @@ def _run_workload(rk, ptamd, shard, tmpdir, config, steps, warmup, spp_arg, dept
         elif spp_count:
             ptamd.Render(cam, pt, film, spp_count, depth, spp_begin=spp_begin, russian_roulette=rr, count=count)
 
+    # Scene set-up, like the commit: the library chooses the schedule of a scene's mesh walks by a measurement at its first
+    # launch of 64 samples and more (ptamd_scene_info.walk_cut), so one such launch is made before anything is timed, also
+    # when the run has no warm-up steps.
+    if spp_count >= 64:
+        if mode == "tile":
+            ptamd.Render(cam, pt, film, 64, depth, russian_roulette=rr, tiles=(32, rank, world))
+        else:
+            ptamd.Render(cam, pt, film, 64, depth, russian_roulette=rr)
     for _ in range(warmup):
         accum.zero_(); samples.zero_()
         launch()
