@@ -628,7 +628,6 @@ int ptamd_scene_commit(ptamd_scene* s)
 }
 static int commit_scene(ptamd_scene* s)
 {
-    s->walk_cut = -1; // an edit changes which walks are long: measured again at the next eligible launch
     const auto t_begin = std::chrono::steady_clock::now();
     auto seconds_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     if (!s->structure_dirty && s->h_objects.size() == s->objects.size()) {
@@ -638,6 +637,8 @@ static int commit_scene(ptamd_scene* s)
         for (size_t i = 0; i < s->objects.size(); ++i) {
             const uint8_t what = s->edits[i];
             if (!what) continue;
+            if (what & 1) s->walk_cut = -1; // a moved object changes which walks are long: the schedule is measured again at the next
+                                            // eligible launch (an edited material leaves the walks as they are)
             const HostObject& ho = s->objects[i];
             DObject& row = s->h_objects[i];
             if (ho.kind == KIND_MESH) {
@@ -683,6 +684,7 @@ static int commit_scene(ptamd_scene* s)
         return PTAMD_OK;
     }
     s->committed = false; // until every buffer of the new state has arrived
+    s->walk_cut = -1;     // new geometry: the walk schedule is measured again at the next eligible launch
     double bvhSeconds = 0.0;
     const int maxDepth = max_stack_depth();
     std::vector<DObject> objects; std::vector<DMesh> meshes; std::vector<DMaterial> materials;

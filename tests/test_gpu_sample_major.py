@@ -272,6 +272,13 @@ def test_deferred_walk_is_chosen_by_measurement(gpu, monkeypatch):
     assert np.array_equal(a.Accum().view(np.uint32), b.Accum().view(np.uint32))
     assert pt.Info()["walk_cut"] == chosen
     monkeypatch.delenv("PTAMD_WALK_DEFER")
+    sphere = pt.GetRayObjects()[7]
+    m = sphere.GetMaterial(); m.roughness = 0.3; sphere.SetMaterial(m); pt.Commit()  # a material edit leaves the walks as they are
+    assert pt.Info()["walk_cut"] == chosen
+    sphere.SetPosition((1.1, 0.6, 1.4)); pt.Commit()                                # a moved object: measured again
+    assert pt.Info()["walk_cut"] == unknown
+    gpu.Render(cam, pt, gpu.Film(1280, 720), 64, 8, seed=3)
+    assert pt.Info()["walk_cut"] in (0, 20, 40)
     two = mixed_blob(1280, 720)
     two["objects"].append(dict(two["objects"][-1], pos=(1.2, 1.0, 3.4)))
     pt2, cam2 = gpu.build_scene(two)
