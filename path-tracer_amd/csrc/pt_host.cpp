@@ -109,6 +109,7 @@ struct ptamd_scene {
     // global memory: the waiting lanes that start a deferred shared walk; 0 = the plain schedule. Measured at the first
     // eligible launch after a commit (tune_walk_cut).
     int walk_cut = -1, walk_cut_w = 0, walk_cut_h = 0, walk_cut_depth = 0;
+    uint32_t walk_cut_uses = 0; // launches that have used the measured schedule
     DScene dscene;
     void release() // what commit rebuilds; the sky map is uploaded by its own call and outlives commits
     {
@@ -637,8 +638,10 @@ static int commit_scene(ptamd_scene* s)
         for (size_t i = 0; i < s->objects.size(); ++i) {
             const uint8_t what = s->edits[i];
             if (!what) continue;
-            if (what & 1) s->walk_cut = -1; // a moved object changes which walks are long: the schedule is measured again at the next
-                                            // eligible launch (an edited material leaves the walks as they are)
+            // A moved object changes which walks are long: the schedule is measured again at the next eligible launch (an edited
+            // material leaves the walks as they are) -- unless the last measurement is under 32 launches old: a session that
+            // moves an object before every frame measures once in 32 frames, not ten probe launches per frame.
+            if ((what & 1) && s->walk_cut_uses >= 32u) s->walk_cut = -1;
             const HostObject& ho = s->objects[i];
             DObject& row = s->h_objects[i];
             if (ho.kind == KIND_MESH) {
@@ -1138,7 +1141,9 @@ static int walk_cut_for(ptamd_scene* s, const DRenderParams& rp, bool may_measur
     if (s->walk_cut < 0 || s->walk_cut_w != rp.cam.width || s->walk_cut_h != rp.cam.height || s->walk_cut_depth != rp.depth) {
         if (!may_measure) return PTAMD_OK;
         if (tune_walk_cut(s, rp) != PTAMD_OK) { (void)hipGetLastError(); s->walk_cut = 0; } // no scratch film: render with the plain schedule
+        s->walk_cut_uses = 0;
     }
+    ++s->walk_cut_uses;
     *out = (uint32_t)s->walk_cut;
     return PTAMD_OK;
 }

@@ -189,7 +189,13 @@ def test_walk_cut_is_measured_once_per_commit_and_leaves_the_film_alone(gpu, mon
     assert pt.Info()["walk_cut"] == chosen          # the variable overrides, it does not overwrite
     monkeypatch.delenv("PTAMD_WALK_BUDGET")
     mesh = pt.GetRayObjects()[0]
-    mesh.SetRotation((0.0, 1.0, 0.0)); pt.Commit()  # an edit: measured again at the next eligible launch
+    mesh.SetRotation((0.0, 1.0, 0.0)); pt.Commit()  # a measurement that fewer than 32 launches have used survives a moved object
+    assert pt.Info()["walk_cut"] == chosen          # (a session that moves something before every frame measures once in 32 frames)
+    scratch = gpu.Film(1280, 720)
+    for _ in range(32):
+        gpu.Render(cam, pt, scratch, 64, 8, seed=3)
+    assert pt.Info()["walk_cut"] == chosen
+    mesh.SetRotation((0.0, 2.0, 0.0)); pt.Commit()  # 32 launches later a move asks for a new measurement at the next eligible launch
     assert pt.Info()["walk_cut"] == unknown
     gpu.Render(cam, pt, gpu.Film(1280, 720), 64, 8, seed=3)
     assert pt.Info()["walk_cut"] in (0, 24)
@@ -275,10 +281,8 @@ def test_deferred_walk_is_chosen_by_measurement(gpu, monkeypatch):
     sphere = pt.GetRayObjects()[7]
     m = sphere.GetMaterial(); m.roughness = 0.3; sphere.SetMaterial(m); pt.Commit()  # a material edit leaves the walks as they are
     assert pt.Info()["walk_cut"] == chosen
-    sphere.SetPosition((1.1, 0.6, 1.4)); pt.Commit()                                # a moved object: measured again
-    assert pt.Info()["walk_cut"] == unknown
-    gpu.Render(cam, pt, gpu.Film(1280, 720), 64, 8, seed=3)
-    assert pt.Info()["walk_cut"] in (0, 20, 40)
+    sphere.SetPosition((1.1, 0.6, 1.4)); pt.Commit()                                # a moved object, few launches since: kept
+    assert pt.Info()["walk_cut"] == chosen
     two = mixed_blob(1280, 720)
     two["objects"].append(dict(two["objects"][-1], pos=(1.2, 1.0, 3.4)))
     pt2, cam2 = gpu.build_scene(two)
