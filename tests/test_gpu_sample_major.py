@@ -288,3 +288,46 @@ def test_deferred_walk_is_chosen_by_measurement(gpu, monkeypatch):
     pt2, cam2 = gpu.build_scene(two)
     gpu.Render(cam2, pt2, gpu.Film(1280, 720), 64, 8, seed=3)
     assert pt2.Info()["walk_cut"] == unknown        # nothing to measure: every search walks both meshes
+
+
+def test_deferred_walk_on_random_scenes(gpu, monkeypatch):
+    """The bounds test that decides which rays wait for the shared walk must never turn away a ray that the walk would
+    have given a hit: random rooms (rotated and unrotated boxes, spheres, some of glass or mirror) in front of a mesh with
+    a random placement -- tiny, larger than the room (camera and every ray origin inside its bounds), flattened by an
+    uneven scale, partly behind the camera -- render the same film bit for bit with every search walking the mesh and
+    with walks deferred until 20 lanes wait or until every lane waits."""
+    rng = np.random.default_rng(20261112)
+    meshes = ["tests/golden/blob.glb", "tests/golden/textured.glb", "tests/golden/cornell_mesh.glb"]
+    for case in range(12):
+        objs = presets.room_without_light()[: int(rng.integers(0, 7))]
+        objs.append({"type": "box", "pos": (2.78, 5.44, 2.8), "rot": (0.0, 0.0, 0.0), "size": (3.0, 0.006, 3.0),
+                     "mat": presets.material(albedo=(0, 0, 0), emission_colour=(1.0, 0.9, 0.8), emission_strength=4.0)})
+        for _ in range(int(rng.integers(0, 4))):
+            kind = rng.integers(0, 3)
+            mat = presets.material(albedo=tuple(rng.uniform(0.2, 1.0, 3)), roughness=float(rng.choice([0.0, 0.3, 1.0])),
+                                   metallic=float(rng.choice([0.0, 1.0])), transmission=float(rng.choice([0.0, 0.0, 1.0])))
+            pos = tuple(rng.uniform(0.5, 5.0, 3))
+            if kind == 0:
+                objs.append({"type": "sphere", "pos": pos, "radius": float(rng.uniform(0.2, 1.0)), "mat": mat})
+            else:
+                objs.append({"type": "box", "pos": pos, "rot": tuple(rng.uniform(-40, 40, 3)) if kind == 1 else (0.0, 0.0, 0.0),
+                             "size": tuple(rng.uniform(0.3, 1.5, 3)), "mat": mat})
+        size = float(rng.choice([0.02, 0.4, 1.0, 2.5, 8.0]))
+        scale = tuple(size * rng.uniform(0.3, 1.0, 3)) if case % 3 else (size, size, size)
+        path = meshes[case % 3]
+        if path.endswith("cornell_mesh.glb"):
+            scale = tuple(0.3 * v for v in scale)  # authored at room size
+        objs.append({"type": "mesh", "path": path, "pos": tuple(rng.uniform(0.5, 5.0, 3)), "rot": tuple(rng.uniform(-180, 180, 3)), "scale": scale})
+        scene = {"film": (64, 48), "camera": presets.default_camera(), "background": (0.3, 0.35, 0.4), "objects": objs}
+        monkeypatch.setenv("PTAMD_NO_LDS_GEOM", "1")  # the small meshes too are read from global memory here
+        pt, cam = gpu.build_scene(scene)
+        assert pt.Info()["lds_resident"] == 0
+        films = []
+        for lanes in ("0", "20", "64"):
+            monkeypatch.setenv("PTAMD_WALK_DEFER", lanes)
+            f = gpu.Film(64, 48)
+            gpu.Render(cam, pt, f, 64, 6, seed=case, russian_roulette=bool(case & 1))
+            films.append(f.Accum())
+        assert np.isfinite(films[0]).all() and float(films[0].mean()) > 0.0
+        for f in films[1:]:
+            assert np.array_equal(films[0].view(np.uint32), f.view(np.uint32)), case
