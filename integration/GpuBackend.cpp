@@ -140,9 +140,9 @@ void GpuBackend::RenderFrame(Camera& _camera, int _depth, bool _albedoOnly, bool
 {
     if (!mFilm) throw std::runtime_error(std::string("ptamd: no film: ") + ptamd_last_error());
     const ptamd_camera c = ToC(_camera);
-    // sample index = frame number: the same (seed, frame) always gives the same pass, on any number of GPUs
-    Check(ptamd_render(mScene, &c, mFilm, mFrame, 1, _depth, _albedoOnly ? 1 : 0, 0x5EEDu, nullptr, 0u));
-    ++mFrame;
+    // sample indices continue from call to call: the same (seed, index) always gives the same sample, on any number of GPUs
+    Check(ptamd_render(mScene, &c, mFilm, mFrame, mSamplesPerFrame, _depth, _albedoOnly ? 1 : 0, 0x5EEDu, nullptr, 0u));
+    mFrame += mSamplesPerFrame;
     _rgba8.resize((size_t)mWidth * mHeight * 4);
     Check(ptamd_film_resolve_rgba8(mFilm, _reinhard ? 1 : 0, _sRGB ? 1 : 0, _rgba8.data()));
 }

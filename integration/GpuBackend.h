@@ -45,6 +45,9 @@ public:
     void ResetAccumulation();             // Film::Reset + frame counter (main.cpp:361-362)
     void Resize(int _width, int _height); // Film::Resize (main.cpp:395-404)
     uint32_t Frames() const { return mFrame; }
+    // Samples per pixel that one RenderFrame call adds (default 1, the reference's pass per UI frame, main.cpp:17-28). The
+    // library's fast kernel takes launches of 64 and more: at 1080p a frame of 64 is still tens of milliseconds.
+    void SetSamplesPerFrame(uint32_t _n) { mSamplesPerFrame = _n ? _n : 1u; }
     int ObjectCount() const;
 
     static ptamd_material ToC(const Material& _m);
@@ -53,7 +56,8 @@ public:
 private:
     ptamd_scene* mScene = nullptr;
     ptamd_film* mFilm = nullptr;
-    uint32_t mFrame = 0;
+    uint32_t mFrame = 0;           // samples per pixel rendered so far = index of the next one
+    uint32_t mSamplesPerFrame = 1;
     int mWidth = 0, mHeight = 0;
     std::map<const RayObject*, std::string> mMeshFiles;
     static void Check(int _rc);

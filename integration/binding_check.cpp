@@ -48,6 +48,9 @@ int main(int argc, char** argv)
         std::vector<uint8_t> rgba;
         for (int f = 0; f < 24; ++f) gpu.RenderFrame(camera, 5, false, true, true, rgba);
         EXPECT(gpu.Frames() == 24 && rgba.size() == (size_t)W * H * 4);
+        gpu.SetSamplesPerFrame(64); // one call, 64 passes: the sample indices go on where the single passes stopped
+        gpu.RenderFrame(camera, 5, false, true, true, rgba);
+        EXPECT(gpu.Frames() == 88);
         size_t lit = 0;
         for (size_t p = 0; p < (size_t)W * H; ++p) lit += (rgba[4 * p] | rgba[4 * p + 1] | rgba[4 * p + 2]) != 0;
         EXPECT(lit > (size_t)W * H / 4);
