@@ -282,9 +282,9 @@ def _run_workload(rk, ptamd, shard, tmpdir, config, steps, warmup, spp_arg, dept
             ptamd.Render(cam, pt, film, spp_count, depth, spp_begin=spp_begin, russian_roulette=rr, count=count)
 
     # Scene set-up, like the commit: the library chooses the schedule of a scene's mesh walks by a measurement at its first
-    # launch of 64 samples and more (ptamd_scene_info.walk_cut), so one such launch is made before anything is timed, also
+    # launch of 16 samples and more (ptamd_scene_info.walk_cut), so one such launch is made before anything is timed, also
     # when the run has no warm-up steps.
-    if spp_count >= 64:
+    if spp_count >= 16:
         if mode == "tile":
             ptamd.Render(cam, pt, film, 64, depth, russian_roulette=rr, tiles=(32, rank, world))
         else:
@@ -350,8 +350,8 @@ def _run_workload(rk, ptamd, shard, tmpdir, config, steps, warmup, spp_arg, dept
                             "per pixel and launch): `achieved` prices the slab / triangle / sphere / box tests and shaded hits this "
                             "kernel executed (its own counters: 27 flop per box test, 47 per triangle test, 25 per sphere, 60 per "
                             "oriented box, 250 per shaded hit) over the launch time" % ("LDS" if lds_resident else "L2 / Infinity Cache / HBM"),
-                    "kernel": ("render_samples_kernel (sample-major: 64 spp and more per launch)"
-                               if 64 <= spp_count <= (1 << 20) and depth >= 2 and not os.environ.get("PTAMD_NO_SAMPLE_MAJOR")
+                    "kernel": ("render_samples_kernel (sample-major: 16 spp and more per launch)"
+                               if 16 <= spp_count <= (1 << 20) and depth >= 2 and not os.environ.get("PTAMD_NO_SAMPLE_MAJOR")
                                else "render_kernel (pixel-major)"), "traffic_unit": "bytes per launch (memory-side counters, PMC passes committed under profiles/)",
                     "traffic_source": traffic_file, "executed_flops_per_sample": flops / max(1, stats["samples"]),
                     "executed_per_ray": {"nodes": stats["nodes"] / max(1, stats["rays"]), "tris": stats["tris"] / max(1, stats["rays"])},

@@ -184,7 +184,7 @@ typedef struct ptamd_scene_info {
     uint32_t walk_cut;           /* LDS-resident scenes whose last object is a mesh: the 64ths of a wave's walking lanes at which a walk
                                     is cut and resumed in the wave's next search. Scenes read from global memory whose only mesh is
                                     their last object: the lanes of a wave that wait at the mesh's bounds before the wave walks it
-                                    for all of them. (0: neither; 0xffffffff: not measured yet, the first launch of 64 spp or more
+                                    for all of them. (0: neither; 0xffffffff: not measured yet, the first launch of 16 spp or more
                                     measures it.) The film does not depend on it */
 } ptamd_scene_info;
 int ptamd_scene_get_info(const ptamd_scene* s, ptamd_scene_info* out);

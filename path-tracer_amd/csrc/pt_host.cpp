@@ -1136,7 +1136,7 @@ static int walk_cut_for(ptamd_scene* s, const DRenderParams& rp, bool may_measur
     const bool cut = s->dscene.lds_resident && s->dscene.tail_mesh;
     const bool defer = !s->dscene.lds_resident && (s->dscene.tail_mesh & 2u);
     if (!cut && !defer) return PTAMD_OK;
-    if (rp.spp_count < 64u || rp.depth < 2 || rp.albedo_only) return PTAMD_OK; // launches that the sample-major kernel does not take
+    if (rp.spp_count < kSampleMajorMinSpp || rp.depth < 2 || rp.albedo_only) return PTAMD_OK; // launches that the sample-major kernel does not take
     if (const char* env = std::getenv(cut ? "PTAMD_WALK_BUDGET" : "PTAMD_WALK_DEFER")) { *out = (uint32_t)std::min(cut ? 63 : 64, std::max(0, std::atoi(env))); return PTAMD_OK; }
     if (s->walk_cut < 0 || s->walk_cut_w != rp.cam.width || s->walk_cut_h != rp.cam.height || s->walk_cut_depth != rp.depth) {
         if (!may_measure) return PTAMD_OK;

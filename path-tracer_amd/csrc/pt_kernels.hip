@@ -640,7 +640,7 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const bool count = rp.counters != nullptr;
     static const bool debug = getenv("PTAMD_DEBUG") != nullptr;
     const bool ext = (rp.flags & kFlagRoulette) != 0 || sc.sky_size > 0;
-    // Many samples per pixel: the sample-major kernel (see render_samples_kernel). Fewer than 64 samples leave its waves too
+    // Many samples per pixel: the sample-major kernel (see render_samples_kernel). Fewer than kSampleMajorMinSpp leave its waves too
     // short-lived; albedo-only and depth < 2 renders end at the camera ray's hit anyway. PTAMD_NO_SAMPLE_MAJOR=1 (read per
     // launch) keeps every launch on the pixel-major kernel.
     const bool noSampleMajor = getenv("PTAMD_NO_SAMPLE_MAJOR") != nullptr;
@@ -657,7 +657,7 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     const bool defer = !fits && (sc.tail_mesh & 2u) != 0u && rp.walk_budget != 0u;
     if (defer) p.walk_budget = rp.walk_budget > 64u ? 64u : rp.walk_budget;
     const size_t ldsSamples = ldsPlain + (budget ? kSamplesParkBytes : 0u);
-    if (!noSampleMajor && rp.spp_count >= 64u && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only
+    if (!noSampleMajor && rp.spp_count >= kSampleMajorMinSpp && rp.spp_count <= kSampleMajorMaxSpp && rp.depth >= 2 && !rp.albedo_only
         && ldsSamples <= kLdsBlockBytes) {
         const int n8 = tiled ? rp.tiles_owned * rp.tile_waves : rp.tiles_x * rp.tiles_y; // 8x8-pixel blocks, one workgroup each
         const int nb = ((n8 + 63) / 64) * 64;                                            // dealt to the XCDs eight neighbours at a time

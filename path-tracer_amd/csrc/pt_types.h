@@ -106,6 +106,11 @@ constexpr uint32_t kLdsNodeBytes = 112;
 // and the hot triangles.
 constexpr uint32_t kLdsBlockBytes = 160 * 1024 / 3;
 constexpr uint32_t kLdsFixedBytes = 4 * 1024; // per workgroup, besides stack and geometry
+// Launches of this many samples per pixel and more run the sample-major kernel (render_samples_kernel). Measured at 1080p,
+// pixel-major against sample-major kernel in Msamples/s: mesh Cornell 3419 / 3184 at 8 samples, 3533 / 3770 at 16, 3625 / 4134
+// at 32; the room around a 100 000-triangle model 1434 / 1514, 1479 / 1860, 1515 / 2093; glass and mirror spheres 6978 / 7040,
+// 7208 / 7250, 7443 / 7756; a million triangles in the room 742 / 751, 761 / 784, 781 / 832.
+constexpr uint32_t kSampleMajorMinSpp = 16;
 
 // Hot triangle in plane form. With n = e1 x e2 (e1 = v1 - v0, e2 = v2 - v0): the determinant of Mesh::RayTriMT
 // (Mesh.cpp:421-431) is -(n . d), its t is (n . v0 - n . o) / (n . d), and the barycentrics of the hit point h

@@ -142,7 +142,7 @@ def test_config2_full_size_properties(gpu, golden):
     f2 = gpu.Film(w, h)
     gpu.Render(cam, pt, f2, 100, 8, spp_begin=0)
     gpu.Render(cam, pt, f2, spp - 100, 8, spp_begin=100)
-    # launches of 64 samples and more on this scene sum their samples exactly and add the sum once: a split moves float rounding
+    # launches of 16 samples and more on this scene sum their samples exactly and add the sum once: a split moves float rounding
     assert np.allclose(f2.Accum()[::7], film.Accum()[::7], rtol=3e-7, atol=1e-7)
 
 
@@ -314,7 +314,8 @@ def test_tiny_meshes(gpu, faces, monkeypatch):
 
 def test_config3_full_combination(gpu, golden, dragon_field_glb):
     """Config 3 as benchmarked: the 1 M-triangle dragon field in the closed room at 1920x1080, without and with the cubemap
-    sky. Exact sample counts; sample ranges add up bit for bit (the kept camera-ray hit of the one-launch render included);
+    sky. Exact sample counts; launches of under 16 samples add up bit for bit (the kept camera-ray hit of the one-launch render
+    included), larger ones to float rounding;
     the frame agrees with the reference's 96x54 golden render of the same view (mean luminance, and pixel by pixel after
     averaging 20x20 blocks, no further from the mean of the reference's two 256-spp runs than those are from each other)."""
     from scenes import dragon
@@ -329,11 +330,17 @@ def test_config3_full_combination(gpu, golden, dragon_field_glb):
     st = gpu.RenderStats()
     assert st["samples"] == w * h * spp and st["steal_rounds"] > 0
     assert np.array_equal(film.Samples(), np.full((h, w), spp, np.uint32))
-    f2 = gpu.Film(w, h)
+    f1, f2 = gpu.Film(w, h), gpu.Film(w, h)
+    gpu.Render(cam, pt, f1, 15, 8)
     gpu.Render(cam, pt, f2, 1, 8, spp_begin=0)
-    gpu.Render(cam, pt, f2, 20, 8, spp_begin=1)
-    gpu.Render(cam, pt, f2, spp - 21, 8, spp_begin=21)
-    assert np.array_equal(f2.Accum()[::5].view(np.uint32), film.Accum()[::5].view(np.uint32))
+    gpu.Render(cam, pt, f2, 6, 8, spp_begin=1)
+    gpu.Render(cam, pt, f2, 8, 8, spp_begin=7)
+    assert np.array_equal(f2.Accum()[::5].view(np.uint32), f1.Accum()[::5].view(np.uint32))
+    gpu.Render(cam, pt, f2, spp - 15, 8, spp_begin=15)  # the rest in one sample-major launch: the one-launch film to rounding
+    # (the two kernels are separate compilations: a last-bit difference now and then sends one sample of a pixel another way)
+    close = np.isclose(f2.Accum()[::5], film.Accum()[::5], rtol=1e-5, atol=1e-6).all(axis=-1)
+    assert close.mean() >= 0.995, float(close.mean())
+    assert abs(float(f2.Accum().mean()) - float(film.Accum().mean())) <= 2e-4 * float(film.Accum().mean())
     A = film.Average()
     assert np.isfinite(A).all()
     ref = 0.5 * (g["avg_a"].astype(np.float32) + g["avg_b"].astype(np.float32))

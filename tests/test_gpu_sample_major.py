@@ -1,4 +1,4 @@
-"""The sample-major render kernel (launches of 64 samples per pixel and more) against
+"""The sample-major render kernel (launches of 16 samples per pixel and more) against
 the pixel-major kernel, which adds a pixel's samples in the reference's order (Film::AddSample, Film.cpp:34-46, called once
 per RayTraceParallel pass, main.cpp:17-28). Both run the same paths -- the random stream is keyed by (pixel, sample) -- so
 ray counts agree and the films differ by float rounding: the sample-major kernel adds the exactly rounded sum of a
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 def both(gpu, scene, spp, depth, spp_begin=0, rect=None, rr=False, seed=5, tiles=None):
-    """(film of one sample-major launch, film of pixel-major launches of < 64 samples each, stats of both)."""
+    """(film of one sample-major launch, film of pixel-major launches of < 16 samples each, stats of both)."""
     pt, cam = gpu.build_scene(scene)
     w, h = scene["film"]
     fs, fp = gpu.Film(w, h), gpu.Film(w, h)
@@ -26,7 +26,7 @@ def both(gpu, scene, spp, depth, spp_begin=0, rect=None, rr=False, seed=5, tiles
     rays = 0
     b = spp_begin
     while b < spp_begin + spp:
-        n = min(50, spp_begin + spp - b)
+        n = min(12, spp_begin + spp - b)
         gpu.Render(cam, pt, fp, n, depth, spp_begin=b, rect=rect, russian_roulette=rr, seed=seed, count=True, tiles=tiles)
         rays += gpu.RenderStats()["rays"]
         b += n
@@ -166,7 +166,7 @@ def test_walk_cut_changes_the_schedule_not_the_film(gpu, name, monkeypatch):
 
 
 def test_walk_cut_is_measured_once_per_commit_and_leaves_the_film_alone(gpu, monkeypatch):
-    """Without the variable the first launch of 64 samples and more on a scene that is one LDS-resident mesh measures whether
+    """Without the variable the first launch of 16 samples and more on a scene that is one LDS-resident mesh measures whether
     the cut pays (two bands of the frame, with and without) and keeps the answer until the next commit; launches that
     cannot use it, the entry point that allocates nothing and small films measure nothing."""
     monkeypatch.delenv("PTAMD_WALK_BUDGET", raising=False)
@@ -175,7 +175,7 @@ def test_walk_cut_is_measured_once_per_commit_and_leaves_the_film_alone(gpu, mon
     unknown = 0xffffffff
     assert pt.Info()["walk_cut"] == unknown
     few = gpu.Film(1280, 720)
-    gpu.Render(cam, pt, few, 8, 8, seed=3)          # under 64 samples: the pixel-major kernel, nothing to measure
+    gpu.Render(cam, pt, few, 8, 8, seed=3)          # under 16 samples: the pixel-major kernel, nothing to measure
     assert pt.Info()["walk_cut"] == unknown
     a = gpu.Film(1280, 720)
     gpu.Render(cam, pt, a, 64, 8, seed=3)
@@ -259,7 +259,7 @@ def test_deferred_walk_changes_the_schedule_not_the_film(gpu, name, monkeypatch,
 
 
 def test_deferred_walk_is_chosen_by_measurement(gpu, monkeypatch):
-    """Without the variable the first launch of 64 samples and more on such a scene measures the plain schedule against
+    """Without the variable the first launch of 16 samples and more on such a scene measures the plain schedule against
     walks deferred until 20 and until 40 lanes wait and keeps the fastest (ptamd_scene_info.walk_cut), once per commit; a
     scene with a second mesh has no deferred walk to choose."""
     monkeypatch.delenv("PTAMD_WALK_DEFER", raising=False)
