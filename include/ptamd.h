@@ -229,6 +229,10 @@ int ptamd_film_device_ptrs(ptamd_film* f, void** d_accum, void** d_samples);
  * rect (NULL = whole film); equals spp_count successive RayTraceParallel passes.  depth and albedo_only are
  * TraceRay's arguments (PathTracer.h:11).  The random stream is keyed by (seed, pixel, sample index, bounce,
  * draw), so any split of the work over calls, rects or GPUs produces the same per-sample values.
+ * How a pixel's samples are added: a call of fewer than 16 samples adds them one by one in the reference's order
+ * (Film::AddSample, Film.cpp:34-46), so passes of that size give the same film bit for bit however they are grouped; a
+ * call of 16 samples and more adds the exactly rounded sum of its samples in one float addition, so regrouping such
+ * calls moves the film by float rounding (1e-7 relative).
  * Asynchronous on the library stream; film reads synchronise. */
 int ptamd_render(ptamd_scene* s, const ptamd_camera* cam, ptamd_film* f, uint32_t spp_begin, uint32_t spp_count,
                  int depth, int albedo_only, uint32_t seed, const ptamd_rect* rect, uint32_t flags);
