@@ -33,6 +33,10 @@ def both(gpu, scene, spp, depth, spp_begin=0, rect=None, rr=False, seed=5, tiles
     return fs, fp, ss, rays
 
 
+def mixed_blob(w, h):
+    return presets.mixed("tests/golden/blob.glb", w, h, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
+
+
 def agree(a, b):
     close = np.isclose(a, b, rtol=1e-5, atol=1e-6).all(axis=-1)
     assert close.mean() >= 0.995, (float(close.mean()), float(np.abs(a - b).max()))
@@ -58,6 +62,27 @@ def test_sample_major_equals_pixel_major(gpu, name):
     f2 = gpu.Film(w, h)
     gpu.Render(cam, pt, f2, 130, depth, spp_begin=7, seed=5)
     assert np.array_equal(a.view(np.uint32), f2.Accum().view(np.uint32))
+
+
+@pytest.mark.parametrize("spp", [16, 23])
+def test_sample_major_at_its_smallest_launches(gpu, spp, monkeypatch):
+    """The kernel takes launches from 16 samples on: four tickets per lane at 16, a ragged last round at 23. Against the
+    pixel-major kernel as above, on an LDS-resident scene (with its walks cut) and on one read from global memory (with its
+    walks deferred); a launch of 15 samples still adds its samples one by one (bit-identical to three launches of 5)."""
+    monkeypatch.setenv("PTAMD_WALK_BUDGET", "24")
+    monkeypatch.setenv("PTAMD_WALK_DEFER", "20")
+    for scene in (presets.mesh_cornell("tests/golden/cornell_mesh.glb", 100, 54), mixed_blob(96, 60)):
+        fs, fp, ss, rays = both(gpu, scene, spp, 8, spp_begin=3)
+        assert np.array_equal(fs.Samples(), fp.Samples()) and int(fs.Samples().min()) == spp
+        agree(fs.Accum(), fp.Accum())
+        w, h = scene["film"]
+        assert ss["samples"] == w * h * spp and abs(ss["rays"] - rays) <= 1e-4 * rays, (ss["rays"], rays)
+        pt, cam = gpu.build_scene(scene)
+        one, three = gpu.Film(w, h), gpu.Film(w, h)
+        gpu.Render(cam, pt, one, 15, 8, seed=5)
+        for k in range(3):
+            gpu.Render(cam, pt, three, 5, 8, spp_begin=5 * k, seed=5)
+        assert np.array_equal(one.Accum().view(np.uint32), three.Accum().view(np.uint32))
 
 
 def test_sample_major_rect_roulette_and_sky(gpu):
@@ -202,10 +227,6 @@ def test_walk_cut_is_measured_once_per_commit_and_leaves_the_film_alone(gpu, mon
     small, cam_s = gpu.build_scene(presets.mesh_cornell("tests/golden/cornell_mesh.glb", 96, 56))
     gpu.Render(cam_s, small, gpu.Film(96, 56), 64, 8, seed=3)
     assert small.Info()["walk_cut"] == 0            # a small film: not worth the launches
-
-
-def mixed_blob(w, h):
-    return presets.mixed("tests/golden/blob.glb", w, h, mesh_pos=(2.6, 1.3, 2.4), mesh_rot=(10.0, 30.0, 5.0), mesh_scale=(1.1, 0.9, 1.0))
 
 
 @pytest.mark.parametrize("name", ["blob_among_primitives", "roulette_sky_tiles", "textured_alpha_mask", "dragon_field_wide_nodes"])
