@@ -1071,7 +1071,7 @@ int ptamd_film_device_ptrs(ptamd_film* f, void** a, void** s)
 // schedule: 50 to 250 ms in all, once per commit and (film size, depth). Films of under two such samples, or of more than
 // 64 Mpixels (the scratch film), are rendered with the plain schedule.
 // PTAMD_WALK_BUDGET=<0..63> (the cut) and PTAMD_WALK_DEFER=<0..64> (the waiting lanes) set them without measuring.
-constexpr uint32_t kWalkCut = 24; // of 64: cut when the lanes still walking are down to 3/8 of those that entered the walk
+constexpr uint32_t kWalkCut = 28; // of 64: cut when the lanes still walking are down to 7/16 of those that entered the walk
 constexpr uint32_t kDeferFew = 20, kDeferMany = 40; // waiting lanes that start a deferred walk
 static int tune_walk_cut(ptamd_scene* s, const DRenderParams& user)
 {

@@ -645,8 +645,8 @@ hipError_t launch_render(const DScene& sc, const DRenderParams& rp, hipStream_t 
     // launch) keeps every launch on the pixel-major kernel.
     const bool noSampleMajor = getenv("PTAMD_NO_SAMPLE_MAJOR") != nullptr;
     // rp.walk_budget (set by the host, 0 = none): the 64ths of a wave's walking lanes at which the LDS kernel cuts a walk and
-    // parks what is left of it (see WalkBudget). Measured on the mesh Cornell at 256 samples, Msamples/s: never 4150; 16: 4435;
-    // 20: 4484; 24: 4517; 32: 4270.
+    // parks what is left of it (see WalkBudget). Measured on the mesh Cornell at 512 samples, Msamples/s: never 4150; 20: 4492;
+    // 22: 4506; 24: 4512; 26: 4519; 28: 4536; 30: 4531; 32: 4526; 34: 4519.
     if (p.walk_budget > 63u) p.walk_budget = 63u;
     const size_t ldsPlain = (size_t)p.stack_depth * sizeof(StackEntry) * kBlock + kSamplesTileBytes + kSamplesCacheBytes + kSamplesKeyBytes
                             + (fits ? geomBytes : (size_t)12 * kBlock);
