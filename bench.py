@@ -283,8 +283,10 @@ def _run_workload(rk, ptamd, shard, tmpdir, config, steps, warmup, spp_arg, dept
 
     # Scene set-up, like the commit: the library chooses the schedule of a scene's mesh walks by a measurement at its first
     # launch of 16 samples and more (ptamd_scene_info.walk_cut), so one such launch is made before anything is timed, also
-    # when the run has no warm-up steps.
-    if spp_count >= 16:
+    # when the run has no warm-up steps. (Nothing to measure: a scene without a mesh, or a schedule fixed through the
+    # environment, as tools/profile_bench.sh does so that the profiler's kernel statistics hold frame launches only.)
+    fixed = os.environ.get("PTAMD_WALK_BUDGET") is not None or os.environ.get("PTAMD_WALK_DEFER") is not None
+    if spp_count >= 16 and pt.Info()["meshes"] > 0 and not fixed:
         if mode == "tile":
             ptamd.Render(cam, pt, film, 64, depth, russian_roulette=rr, tiles=(32, rank, world))
         else:
